@@ -1,0 +1,224 @@
+/*
+ * stark_mi.h -- C ABI of libstarkmi.so, the MI355X (gfx950) engine that stands behind
+ * stark-rs's univariate / trace / fri / merkle API.
+ *
+ * The reference (0xSooki/stark-rs @ 2026-01-02) has no FFI of its own:
+ * each entry point below names the Rust inherent method it replaces (file:line under
+ * /root/reference) -- that method's body becomes a call to this function in the
+ * binding shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - Field values cross the boundary as contiguous little-endian u64, the reference's
+ *     wire width (src/stream.rs:45, src/hash.rs:33).  They must be canonical (< p)
+ *     unless a parameter says "unreduced ok" (SURVEY H6).
+ *   - Digests are 32 raw bytes (src/hash.rs:1-2).
+ *   - Every function returns an int32 status: 0 = ok, negative = the reference's panic
+ *     (one code per message, smi_status_string gives the identical text so the Rust
+ *     wrapper can `panic!` with it), <= -100 = HIP/runtime failure (smi_last_error).
+ *   - No C++ exceptions, torch types or caller pointers retained across calls.
+ *   - Functions named smi_dev_* take device pointers (u32 canonical residues, 4 B per
+ *     element on device) and enqueue on the context's stream without synchronising.
+ *     All others take host buffers and are synchronous on return.
+ *   - A context is single-owner (not thread-safe), one per GPU / process.
+ */
+#ifndef STARK_MI_H
+#define STARK_MI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes: the reference's panic messages ------------------------------- */
+enum {
+    SMI_OK = 0,
+    SMI_ERR_NO_INVERSE = -1,          /* "no inverse"                         src/ff.rs:171 */
+    SMI_ERR_DIV_BY_ZERO = -2,         /* "no division by zero"                src/ff.rs:182 */
+    SMI_ERR_NOT_POW2 = -3,            /* "n must be a power of two"           src/ff.rs:217 */
+    SMI_ERR_ROOT_TOO_LARGE = -4,      /* "n > 2^23 not supported by this modulus" src/ff.rs:218 */
+    SMI_ERR_EMPTY_LEAVES = -5,        /* "Cannot create tree from empty leaves"   src/merkle.rs:12 */
+    SMI_ERR_LEAVES_NOT_POW2 = -6,     /* "Number of leaves must be power of 2"    src/merkle.rs:13-16 */
+    SMI_ERR_INDEX_OOB = -7,           /* "Index out of bounds"                src/merkle.rs:68 */
+    SMI_ERR_DOMAIN_NOT_POW2 = -8,     /* "Domain length must be power of 2"   src/fri.rs:37-40 */
+    SMI_ERR_EXPANSION_NOT_POW2 = -9,  /* "Expansion factor must be power of 2" src/fri.rs:41-44 */
+    SMI_ERR_EXPANSION_TOO_SMALL = -10,/* "Expansion factor must be at least 4" src/fri.rs:45 */
+    SMI_ERR_CODEWORD_LEN = -11,       /* "initial codeword length does not match domain length" src/fri.rs:256-260 */
+    SMI_ERR_SAMPLE_ENTROPY = -12,     /* "not enough entropy in indices wrt last codeword" src/fri.rs:183-186 */
+    SMI_ERR_SAMPLE_TOO_MANY = -13,    /* "cannot sample more indices than available in last codeword" src/fri.rs:187-192 */
+    SMI_ERR_LEN_MISMATCH = -14,       /* assert!(domain.len() == values.len()) src/univariate/interpolate.rs:10 */
+    SMI_ERR_EMPTY_DOMAIN = -15,       /* assert!(domain.len() > 0)            src/univariate/interpolate.rs:11 */
+    SMI_ERR_WRONG_FIELD = -16,        /* assert!(self.p == 998244353)         src/ff.rs:192,216 */
+    SMI_ERR_NO_ROUNDS = -17,          /* num_rounds()==0: proof the reference's verify rejects */
+    /* contract violations that have no reference counterpart */
+    SMI_ERR_BAD_ARG = -50,
+    SMI_ERR_NON_CANONICAL = -51,      /* a field value >= p where the precondition forbids it (H6) */
+    SMI_ERR_UNSUPPORTED_PRIME = -52,  /* p must be an odd prime < 2^31 with p-1 divisible by the sizes used */
+    SMI_ERR_NOT_GEOMETRIC = -53,      /* domain is not offset*omega^k: caller must fall back to the CPU code */
+    /* runtime */
+    SMI_ERR_HIP = -100,
+    SMI_ERR_NO_DEVICE = -101,
+    SMI_ERR_OOM = -102
+};
+
+typedef struct smi_ctx smi_ctx;
+typedef struct smi_tree smi_tree;     /* device-resident MerkleTree (all levels) */
+typedef struct smi_fri_run smi_fri_run; /* device-resident artefacts of one Fri::commit */
+
+const char *smi_status_string(int status);
+const char *smi_last_error(const smi_ctx *ctx);
+const char *smi_version(void);
+
+/* ---- context -------------------------------------------------------------------- */
+/* FiniteField::new(p) (src/ff.rs:109-111) plus the generator g() (src/ff.rs:191-197):
+ * (998244353, 3) is the reference field; (2013265921, 31) is the build's second prime
+ * for domains above 2^23.  device = HIP device ordinal. */
+int smi_ctx_create(uint64_t p, uint64_t g, int device, smi_ctx **out);
+void smi_ctx_destroy(smi_ctx *ctx);
+/* Use an existing hipStream_t (e.g. torch's current stream) for everything enqueued. */
+int smi_ctx_set_stream(smi_ctx *ctx, void *hip_stream);
+int smi_ctx_sync(smi_ctx *ctx);
+uint64_t smi_ctx_modulus(const smi_ctx *ctx);
+uint32_t smi_ctx_two_adicity(const smi_ctx *ctx);
+
+/* ---- field scalars (host, exact restatements needed by callers) ------------------ */
+/* FiniteField::prim_nth_root (src/ff.rs:215-223): g^((p-1)/n). */
+int smi_prim_nth_root(const smi_ctx *ctx, uint64_t n, uint64_t *out);
+/* FiniteField::inv via Fermat; SMI_ERR_NO_INVERSE for 0 (src/ff.rs:169-178). */
+int smi_ff_inv(const smi_ctx *ctx, uint64_t x, uint64_t *out);
+int smi_ff_exp(const smi_ctx *ctx, uint64_t base, uint64_t e, uint64_t *out); /* src/ff.rs:200-213 */
+int smi_ff_mul(const smi_ctx *ctx, uint64_t a, uint64_t b, uint64_t *out);    /* src/ff.rs:138-144 */
+
+/* ---- univariate: host-buffer entry points ---------------------------------------- */
+/* Polynomial::interpolate_domain (src/univariate/interpolate.rs:6-44) for the geometric
+ * domain d[k] = offset * omega_n^k, n = 2^log_n, omega_n = prim_nth_root(n):
+ * coeffs[j] = offset^-j n^-1 sum_k values[k] omega_n^-jk.  Always writes n coefficients
+ * (trailing zeros included); Polynomial equality ignores them (src/univariate/mod.rs:13-39). */
+int smi_intt(smi_ctx *ctx, const uint64_t *values, uint64_t *coeffs, uint32_t log_n, uint64_t offset);
+/* Polynomial::eval_domain (src/univariate/eval.rs:16-21) on d[k] = offset * omega_N^k,
+ * N = 2^log_N, n_coeffs <= N: evals[k] = sum_j coeffs[j] d[k]^j, in domain order. */
+int smi_coset_ntt(smi_ctx *ctx, const uint64_t *coeffs, size_t n_coeffs, uint64_t *evals, uint32_t log_N,
+                  uint64_t offset);
+/* Polynomial::scale (src/univariate/mod.rs:99-113): out[i] = coeffs[i] * factor^i. */
+int smi_poly_scale(smi_ctx *ctx, const uint64_t *coeffs, size_t n, uint64_t factor, uint64_t *out);
+/* Checks in O(n) whether domain[k] == domain[0]*omega_n^k (the fast-path contract of
+ * interpolate_domain / eval_domain); returns SMI_OK and *offset = domain[0], or
+ * SMI_ERR_NOT_GEOMETRIC. */
+int smi_domain_is_geometric(const smi_ctx *ctx, const uint64_t *domain, size_t n, uint64_t *offset);
+
+/* ---- trace: Trace::get_col / to_field_elements (src/trace.rs:21-34) --------------- */
+/* Low-degree extension of a column-major trace: for each of n_cols columns (n = 2^log_n
+ * values on the subgroup domain trace_offset*omega_n^k) interpolate, then evaluate on
+ * lde_offset*omega_N^k, N = n << log_blowup.  out is column-major n_cols x N. */
+int smi_lde(smi_ctx *ctx, const uint64_t *cols, uint32_t n_cols, uint32_t log_n, uint32_t log_blowup,
+            uint64_t trace_offset, uint64_t lde_offset, uint64_t *out);
+/* Row-major i128 trace (src/trace.rs:4-7, each value as 16 LE bytes) -> column-major u64,
+ * `e as u64` then reduced mod p for the device (precondition H6 made explicit). */
+int smi_trace_pack(const smi_ctx *ctx, const void *rows_i128, size_t n_rows, size_t n_cols, uint64_t *cols_out);
+
+/* ---- hash / merkle ---------------------------------------------------------------- */
+/* Hash::from_field_elements(&[e]) for each e (src/hash.rs:32-35 as used at src/fri.rs:118-121):
+ * digests gets n x 32 bytes. */
+int smi_hash_leaves(smi_ctx *ctx, const uint64_t *elems, size_t n, uint8_t *digests);
+/* Hash::combine (src/hash.rs:41-46) for n pairs: out[i] = H(left_right[2i] || left_right[2i+1]). */
+int smi_hash_combine_pairs(smi_ctx *ctx, const uint8_t *digests, size_t n_pairs, uint8_t *out);
+/* Hash::from_bytes (src/hash.rs:7-30) of one message (device single-lane kernel). */
+int smi_hash_bytes(smi_ctx *ctx, const uint8_t *msg, size_t len, uint8_t out[32]);
+/* MerkleTree::commit (src/merkle.rs:44-65). */
+int smi_merkle_commit(smi_ctx *ctx, const uint8_t *leaves, size_t n, uint8_t root[32]);
+/* MerkleTree::new (src/merkle.rs:11-38); the tree (all levels) stays on the device. */
+int smi_merkle_new(smi_ctx *ctx, const uint8_t *leaves, size_t n, smi_tree **out);
+/* Fused leaf hashing + tree over a codeword, one element per leaf (src/fri.rs:118-127). */
+int smi_merkle_from_codeword(smi_ctx *ctx, const uint64_t *codeword, size_t n, smi_tree **out);
+int smi_merkle_root(smi_ctx *ctx, const smi_tree *t, uint8_t root[32]);          /* get_root, src/merkle.rs:40-42 */
+/* MerkleTree::open (src/merkle.rs:67-80): path gets *depth = log2(n) digests. */
+int smi_merkle_open(smi_ctx *ctx, const smi_tree *t, size_t index, uint8_t *path, size_t *depth);
+/* Copies level `level` (0 = leaves) to the host: nodes[level] of src/merkle.rs:6. */
+int smi_merkle_level(smi_ctx *ctx, const smi_tree *t, uint32_t level, uint8_t *out, size_t *n_out);
+size_t smi_merkle_num_leaves(const smi_tree *t);
+void smi_merkle_free(smi_tree *t);
+
+/* ---- fri --------------------------------------------------------------------------- */
+/* Fri::new's fields (src/fri.rs:8-15,30-55). */
+typedef struct {
+    uint64_t omega;
+    uint64_t offset;
+    uint64_t domain_length;
+    uint64_t expansion_factor;
+    uint64_t num_colinearity_tests;
+} smi_fri_cfg;
+
+int smi_fri_check(const smi_ctx *ctx, const smi_fri_cfg *cfg);                   /* asserts of src/fri.rs:37-45 */
+int smi_fri_num_rounds(const smi_fri_cfg *cfg, uint64_t *rounds);                /* src/fri.rs:93-103 */
+/* Fri::fold_codeword (src/fri.rs:57-91); alpha may be an unreduced u64 (src/fiat_shamir.rs:23-24). */
+int smi_fri_fold(smi_ctx *ctx, const uint64_t *codeword, size_t len, uint64_t alpha, uint64_t offset,
+                 uint64_t omega, uint64_t *out);
+/* Fri::commit (src/fri.rs:105-156) with a fresh FiatShamir: roots gets R x 32 bytes, alphas
+ * R-1 unreduced challenges, last_codeword domain_length >> (R-1) values.  *run (optional)
+ * keeps codewords and trees on the device for smi_fri_query_run. */
+int smi_fri_commit(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint64_t *codeword, size_t len, uint8_t *roots,
+                   uint64_t *alphas, uint64_t *last_codeword, size_t *last_len, smi_fri_run **run);
+/* Fri::prove (src/fri.rs:250-311) with a fresh FiatShamir and ProofStream, returning
+ * ProofStream::serialize (src/stream.rs:35-64).  *proof is malloc'd: release with smi_free.
+ * top_indices gets num_colinearity_tests entries (the method's return value). */
+int smi_fri_prove(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint64_t *codeword, size_t len, uint8_t **proof,
+                  size_t *proof_len, uint64_t *top_indices);
+void smi_fri_run_free(smi_fri_run *run);
+void smi_free(void *p);
+
+/* ---- device-resident entry points (u32 residues, context stream, no sync) ---------- */
+int smi_dev_alloc(smi_ctx *ctx, size_t bytes, void **d_ptr);
+int smi_dev_free(smi_ctx *ctx, void *d_ptr);
+/* u64 host -> u32 device (checks canonical unless reduce != 0) and back. */
+int smi_dev_upload_u64(smi_ctx *ctx, const uint64_t *host, size_t n, uint32_t *d_out, int reduce);
+int smi_dev_download_u64(smi_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t *host);
+
+/* Batched NTT kernel driver.  For each of `batch` columns (column c at d_in + c*in_stride,
+ * d_out + c*out_stride, strides in elements):
+ *   inverse == 0: out[k] = sum_{j<n_in} in[j] (offset*omega_N^k)^j        (coset NTT, zero-padded)
+ *   inverse != 0: out[j] = scale * offset^-j N^-1 sum_k in[k] omega_N^-jk (n_in must equal N)
+ * N = 2^log_n; natural order in and out; d_in may equal d_out (columns must not overlap).
+ * post_scale (canonical, 1 = none) multiplies every output of the inverse transform by
+ * post_scale^j -- the fused `Polynomial::scale` (src/univariate/mod.rs:99-113) of an LDE. */
+int smi_dev_ntt(smi_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint32_t log_n, size_t n_in, uint32_t batch,
+                size_t in_stride, size_t out_stride, int inverse, uint64_t offset, uint64_t post_scale);
+/* LDE of a column-major device trace: d_out is n_cols x (n << log_blowup), stride N. */
+int smi_dev_lde(smi_ctx *ctx, const uint32_t *d_cols, uint32_t n_cols, uint32_t log_n, uint32_t log_blowup,
+                uint64_t trace_offset, uint64_t lde_offset, uint32_t *d_out);
+/* Leaf digests only / fused leaf hashing + all tree levels.  d_nodes: (2n-1) x 32 bytes,
+ * level 0 (leaf digests) first, root last -- `nodes` of src/merkle.rs:18-33 back to back. */
+int smi_dev_hash_leaves(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_digests);
+int smi_dev_merkle_build(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_nodes);
+/* Tree over precomputed 32-byte leaves already at d_nodes[0 .. n*32). */
+int smi_dev_merkle_from_digests(smi_ctx *ctx, size_t n, uint8_t *d_nodes);
+/* Fri::fold_codeword with alpha read from device memory (*d_alpha: one unreduced u64). */
+int smi_dev_fri_fold(smi_ctx *ctx, const uint32_t *d_in, size_t len, const uint64_t *d_alpha, uint64_t offset,
+                     uint64_t omega, uint32_t *d_out);
+/* Fri::commit + the query phase of Fri::prove over a device codeword.  Roots, alphas and
+ * the serialized proof are produced without a host round trip per round: Fiat-Shamir and
+ * index sampling run in single-lane device kernels. */
+int smi_dev_fri_prove(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, size_t len, uint8_t **proof,
+                      size_t *proof_len, uint64_t *top_indices, smi_fri_run **run);
+
+/* Four-step NTT building blocks for one transform sharded over G GPUs: one
+ * process per GPU; the all-to-all between the two local steps belongs to the caller
+ * (RCCL via torch.distributed -- stark_rs_amd/fourstep.py).  N = R*C points viewed as an
+ * R x C row-major matrix x[r*C + c]; rank g owns columns c0 .. c0 + C/G, stored
+ * column-major (each column R contiguous values).
+ *   1. smi_dev_ntt(batch = C/G, log_n = log R, offset = offset^C) transforms every column;
+ *   2. smi_dev_fourstep_twiddle_pack multiplies element (c, kr) by offset^c * w_N^(kr*c)
+ *      (w_N^-1 when inverse) and writes it into the send layout [G][C/G][R/G]
+ *      (destination rank = kr / (R/G));
+ *   3. all-to-all; the receive buffer is the matrix [C][R/G] of this rank's row block;
+ *   4. smi_dev_transpose to [R/G][C], smi_dev_ntt(batch = R/G, log_n = log C), and
+ *      smi_dev_transpose back to [C][R/G]: row kc holds X[kc*R + g*R/G + i], i < R/G. */
+int smi_dev_fourstep_twiddle_pack(smi_ctx *ctx, const uint32_t *d_cols, uint32_t *d_send, uint32_t log_r, uint32_t log_c,
+                                  uint32_t c0, uint32_t n_local_cols, uint32_t n_ranks, int inverse, uint64_t offset);
+/* out[c*rows + r] = in[r*cols + c] for a rows x cols matrix of u32 (LDS-tiled). */
+int smi_dev_transpose(smi_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, size_t rows, size_t cols);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STARK_MI_H */

@@ -1,0 +1,534 @@
+// api.hip -- context management and the extern "C" surface declared in include/stark_mi.h.
+#include "hash_core.h"
+#include "internal.h"
+
+int launch_leaf_hash(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_digests);
+int launch_combine(smi_ctx *ctx, const uint8_t *d_in, size_t n_pairs, uint8_t *d_out);
+int launch_hash_bytes(smi_ctx *ctx, const uint8_t *d_msg, size_t len, uint32_t *d_out);
+int launch_merkle(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_nodes);
+
+// ------------------------------------------------------------------------- errors
+const char *smi_status_string(int status) {
+    switch (status) {
+    case SMI_OK: return "ok";
+    case SMI_ERR_NO_INVERSE: return "no inverse";
+    case SMI_ERR_DIV_BY_ZERO: return "no division by zero";
+    case SMI_ERR_NOT_POW2: return "n must be a power of two";
+    case SMI_ERR_ROOT_TOO_LARGE: return "n > 2^23 not supported by this modulus";
+    case SMI_ERR_EMPTY_LEAVES: return "Cannot create tree from empty leaves";
+    case SMI_ERR_LEAVES_NOT_POW2: return "Number of leaves must be power of 2";
+    case SMI_ERR_INDEX_OOB: return "Index out of bounds";
+    case SMI_ERR_DOMAIN_NOT_POW2: return "Domain length must be power of 2";
+    case SMI_ERR_EXPANSION_NOT_POW2: return "Expansion factor must be power of 2";
+    case SMI_ERR_EXPANSION_TOO_SMALL: return "Expansion factor must be at least 4";
+    case SMI_ERR_CODEWORD_LEN: return "initial codeword length does not match domain length";
+    case SMI_ERR_SAMPLE_ENTROPY: return "not enough entropy in indices wrt last codeword";
+    case SMI_ERR_SAMPLE_TOO_MANY: return "cannot sample more indices than available in last codeword";
+    case SMI_ERR_LEN_MISMATCH: return "assertion failed: domain.len() == values.len()";
+    case SMI_ERR_EMPTY_DOMAIN: return "assertion failed: domain.len() > 0";
+    case SMI_ERR_WRONG_FIELD: return "assertion failed: self.p == 998244353";
+    case SMI_ERR_NO_ROUNDS: return "No FRI roots extracted";
+    case SMI_ERR_BAD_ARG: return "bad argument";
+    case SMI_ERR_NON_CANONICAL: return "field value not canonical (>= p)";
+    case SMI_ERR_UNSUPPORTED_PRIME: return "unsupported modulus for this size";
+    case SMI_ERR_NOT_GEOMETRIC: return "domain is not offset*omega^k";
+    case SMI_ERR_HIP: return "HIP runtime error";
+    case SMI_ERR_NO_DEVICE: return "no usable HIP device";
+    case SMI_ERR_OOM: return "out of memory";
+    default: return "unknown status";
+    }
+}
+const char *smi_version(void) { return "stark-mi 0.1 (gfx950)"; }
+const char *smi_last_error(const smi_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int smi_fail(smi_ctx *ctx, int code, const char *msg) {
+    if (ctx) ctx->err = msg ? msg : smi_status_string(code);
+    return code;
+}
+int smi_hip_fail(smi_ctx *ctx, hipError_t e, const char *what) {
+    if (ctx) ctx->err = std::string(what) + ": " + hipGetErrorString(e);
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? SMI_ERR_OOM : SMI_ERR_HIP;
+}
+
+// ------------------------------------------------------------------------- context
+int smi_ctx_create(uint64_t p, uint64_t g, int device, smi_ctx **out) {
+    if (!out) return SMI_ERR_BAD_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return SMI_ERR_NO_DEVICE;
+    smi_ctx *ctx = new smi_ctx();
+    if (!field_setup(p, g, &ctx->fs)) {
+        delete ctx;
+        return SMI_ERR_UNSUPPORTED_PRIME;
+    }
+    ctx->device = device;
+    int rc = SMI_OK;
+    do {
+        if (hipSetDevice(device) != hipSuccess) { rc = SMI_ERR_NO_DEVICE; break; }
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { rc = SMI_ERR_HIP; break; }
+        ctx->own_stream = true;
+        if (hipMalloc((void **)&ctx->d_flag, sizeof(int)) != hipSuccess) { rc = SMI_ERR_OOM; break; }
+        if (hipMemsetAsync(ctx->d_flag, 0, sizeof(int), ctx->stream) != hipSuccess) { rc = SMI_ERR_HIP; break; }
+        for (int dir = 0; dir < 2 && rc == SMI_OK; dir++) {
+            GeomSpec sp[3];
+            ntt_table_specs(ctx->fs, dir, sp);
+            for (int k = 0; k < 3 && rc == SMI_OK; k++) {
+                if (hipMalloc((void **)&ctx->d_tab[dir][k], (size_t)sp[k].count * 4) != hipSuccess) { rc = SMI_ERR_OOM; break; }
+                rc = launch_geom_table(ctx, sp[k], ctx->d_tab[dir][k]);
+            }
+        }
+        if (rc != SMI_OK) break;
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = SMI_ERR_HIP; break; }
+    } while (0);
+    if (rc != SMI_OK) {
+        smi_ctx_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return SMI_OK;
+}
+
+void smi_ctx_destroy(smi_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (int d = 0; d < 2; d++)
+        for (int k = 0; k < 3; k++) (void)hipFree(ctx->d_tab[d][k]);
+    for (ScaleEntry &e : ctx->scale_cache) {
+        (void)hipFree(e.lo);
+        (void)hipFree(e.hi);
+    }
+    (void)hipFree(ctx->scratch);
+    for (int i = 0; i < 4; i++) (void)hipFree(ctx->tmp[i]);
+    (void)hipFree(ctx->d_flag);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int smi_ctx_set_stream(smi_ctx *ctx, void *hip_stream) {
+    if (!ctx) return SMI_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
+    return SMI_OK;
+}
+int smi_ctx_sync(smi_ctx *ctx) {
+    if (!ctx) return SMI_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SMI_OK;
+}
+uint64_t smi_ctx_modulus(const smi_ctx *ctx) { return ctx ? ctx->fs.F.p : 0; }
+uint32_t smi_ctx_two_adicity(const smi_ctx *ctx) { return ctx ? ctx->fs.K : 0; }
+
+int ctx_tmp(smi_ctx *ctx, int slot, size_t bytes, void **out) {
+    if (bytes > ctx->tmp_bytes[slot]) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->tmp[slot]);
+        ctx->tmp[slot] = nullptr;
+        ctx->tmp_bytes[slot] = 0;
+        const size_t want = bytes + bytes / 4 + 256;
+        if (hipMalloc(&ctx->tmp[slot], want) != hipSuccess) return smi_fail(ctx, SMI_ERR_OOM, "hipMalloc staging buffer");
+        ctx->tmp_bytes[slot] = want;
+    }
+    *out = ctx->tmp[slot];
+    return SMI_OK;
+}
+int ctx_scratch(smi_ctx *ctx, size_t elems, uint32_t **out) {
+    if (elems > ctx->scratch_elems) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->scratch);
+        ctx->scratch = nullptr;
+        ctx->scratch_elems = 0;
+        if (hipMalloc((void **)&ctx->scratch, elems * 4) != hipSuccess) return smi_fail(ctx, SMI_ERR_OOM, "hipMalloc NTT scratch");
+        ctx->scratch_elems = elems;
+    }
+    *out = ctx->scratch;
+    return SMI_OK;
+}
+NttTables ctx_tables(const smi_ctx *ctx, int inverse) {
+    const int d = inverse ? 1 : 0;
+    return NttTables{ctx->d_tab[d][0], ctx->d_tab[d][1], ctx->d_tab[d][2], ctx->fs.K, ntt_table_h(ctx->fs.K)};
+}
+int ctx_scale_tables(smi_ctx *ctx, uint32_t c_plain, uint32_t q_plain, uint32_t L, ScaleTables *out) {
+    for (const ScaleEntry &e : ctx->scale_cache)
+        if (e.c == c_plain && e.q == q_plain && e.L == L) {
+            *out = ScaleTables{e.lo, e.hi, scale_table_h(L)};
+            return SMI_OK;
+        }
+    if (ctx->scale_cache.size() >= 96) {  // drop the oldest half; in-flight kernels may still read them
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (size_t i = 0; i < 48; i++) {
+            (void)hipFree(ctx->scale_cache[i].lo);
+            (void)hipFree(ctx->scale_cache[i].hi);
+        }
+        ctx->scale_cache.erase(ctx->scale_cache.begin(), ctx->scale_cache.begin() + 48);
+    }
+    GeomSpec sp[2];
+    scale_table_specs(ctx->fs.F, c_plain, q_plain, L, sp);
+    ScaleEntry e{c_plain, q_plain, L, nullptr, nullptr};
+    if (hipMalloc((void **)&e.lo, (size_t)sp[0].count * 4) != hipSuccess) return smi_fail(ctx, SMI_ERR_OOM, "hipMalloc scale table");
+    if (hipMalloc((void **)&e.hi, (size_t)sp[1].count * 4) != hipSuccess) {
+        (void)hipFree(e.lo);
+        return smi_fail(ctx, SMI_ERR_OOM, "hipMalloc scale table");
+    }
+    int rc = launch_geom_table(ctx, sp[0], e.lo);
+    if (rc == SMI_OK) rc = launch_geom_table(ctx, sp[1], e.hi);
+    if (rc != SMI_OK) {
+        (void)hipFree(e.lo);
+        (void)hipFree(e.hi);
+        return rc;
+    }
+    ctx->scale_cache.push_back(e);
+    *out = ScaleTables{e.lo, e.hi, scale_table_h(L)};
+    return SMI_OK;
+}
+int check_flag(smi_ctx *ctx) {
+    int flag = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&flag, ctx->d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (flag) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_flag, 0, sizeof(int), ctx->stream));
+        return smi_fail(ctx, SMI_ERR_NON_CANONICAL, "input field value >= p");
+    }
+    return SMI_OK;
+}
+
+// ------------------------------------------------------------------------- field scalars
+static bool is_pow2(uint64_t n) { return n && !(n & (n - 1)); }
+static uint32_t ilog2(uint64_t n) {
+    uint32_t l = 0;
+    while ((n >> l) > 1) l++;
+    return l;
+}
+
+int smi_prim_nth_root(const smi_ctx *ctx, uint64_t n, uint64_t *out) {
+    if (!ctx || !out) return SMI_ERR_BAD_ARG;
+    if (!is_pow2(n)) return SMI_ERR_NOT_POW2;                      // src/ff.rs:217
+    const uint32_t p = ctx->fs.F.p;
+    if (ilog2(n) > ctx->fs.K) return p == 998244353u ? SMI_ERR_ROOT_TOO_LARGE : SMI_ERR_UNSUPPORTED_PRIME;  // src/ff.rs:218
+    *out = host_powmod(ctx->fs.g, (p - 1) / n, p);                 // g^((p-1)/n), src/ff.rs:220-222
+    return SMI_OK;
+}
+int smi_ff_inv(const smi_ctx *ctx, uint64_t x, uint64_t *out) {
+    if (!ctx || !out) return SMI_ERR_BAD_ARG;
+    const uint32_t p = ctx->fs.F.p;
+    if (x % p == 0) return SMI_ERR_NO_INVERSE;
+    *out = h_inv(ctx, (uint32_t)(x % p));
+    return SMI_OK;
+}
+int smi_ff_exp(const smi_ctx *ctx, uint64_t base, uint64_t e, uint64_t *out) {
+    if (!ctx || !out) return SMI_ERR_BAD_ARG;
+    *out = h_pow(ctx, (uint32_t)(base % ctx->fs.F.p), e);
+    return SMI_OK;
+}
+int smi_ff_mul(const smi_ctx *ctx, uint64_t a, uint64_t b, uint64_t *out) {
+    if (!ctx || !out) return SMI_ERR_BAD_ARG;
+    const uint32_t p = ctx->fs.F.p;
+    *out = h_mul(ctx, (uint32_t)(a % p), (uint32_t)(b % p));
+    return SMI_OK;
+}
+int smi_domain_is_geometric(const smi_ctx *ctx, const uint64_t *domain, size_t n, uint64_t *offset) {
+    if (!ctx || !domain || !n) return SMI_ERR_BAD_ARG;
+    if (!is_pow2(n) || ilog2(n) > ctx->fs.K) return SMI_ERR_NOT_GEOMETRIC;
+    const uint32_t p = ctx->fs.F.p, w = h_root(ctx, ilog2(n));
+    if (domain[0] == 0 || domain[0] >= p) return SMI_ERR_NOT_GEOMETRIC;
+    uint32_t x = (uint32_t)domain[0];
+    for (size_t k = 1; k < n; k++) {
+        x = host_mulmod(x, w, p);
+        if (domain[k] != x) return SMI_ERR_NOT_GEOMETRIC;
+    }
+    if (offset) *offset = domain[0];
+    return SMI_OK;
+}
+
+// ------------------------------------------------------------------------- device memory
+int smi_dev_alloc(smi_ctx *ctx, size_t bytes, void **d_ptr) {
+    if (!ctx || !d_ptr) return SMI_ERR_BAD_ARG;
+    if (hipMalloc(d_ptr, bytes ? bytes : 1) != hipSuccess) return smi_fail(ctx, SMI_ERR_OOM, "hipMalloc");
+    return SMI_OK;
+}
+int smi_dev_free(smi_ctx *ctx, void *d_ptr) {
+    if (!ctx) return SMI_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(d_ptr));
+    return SMI_OK;
+}
+int smi_dev_upload_u64(smi_ctx *ctx, const uint64_t *host, size_t n, uint32_t *d_out, int reduce) {
+    if (!ctx || (!host && n) || (!d_out && n)) return SMI_ERR_BAD_ARG;
+    if (!n) return SMI_OK;
+    void *stage;
+    SMI_TRY(ctx_tmp(ctx, 0, n * 8, &stage));
+    HIP_TRY(ctx, hipMemcpyAsync(stage, host, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    SMI_TRY(launch_narrow(ctx, (const uint64_t *)stage, d_out, n, reduce));
+    return check_flag(ctx);
+}
+int smi_dev_download_u64(smi_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t *host) {
+    if (!ctx || (!host && n) || (!d_in && n)) return SMI_ERR_BAD_ARG;
+    if (!n) return SMI_OK;
+    void *stage;
+    SMI_TRY(ctx_tmp(ctx, 0, n * 8, &stage));
+    SMI_TRY(launch_widen(ctx, d_in, (uint64_t *)stage, n));
+    HIP_TRY(ctx, hipMemcpyAsync(host, stage, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SMI_OK;
+}
+
+// ------------------------------------------------------------------------- univariate
+int smi_dev_ntt(smi_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint32_t log_n, size_t n_in, uint32_t batch,
+                size_t in_stride, size_t out_stride, int inverse, uint64_t offset, uint64_t post_scale) {
+    if (!ctx || !d_in || !d_out) return SMI_ERR_BAD_ARG;
+    return dev_ntt(ctx, d_in, d_out, log_n, n_in, batch, in_stride, out_stride, inverse, offset, post_scale);
+}
+
+int smi_dev_lde(smi_ctx *ctx, const uint32_t *d_cols, uint32_t n_cols, uint32_t log_n, uint32_t log_blowup,
+                uint64_t trace_offset, uint64_t lde_offset, uint32_t *d_out) {
+    if (!ctx || !d_cols || !d_out) return SMI_ERR_BAD_ARG;
+    const uint32_t log_N = log_n + log_blowup;
+    if (log_N > ctx->fs.K) return smi_fail(ctx, ctx->fs.F.p == 998244353u ? SMI_ERR_ROOT_TOO_LARGE : SMI_ERR_UNSUPPORTED_PRIME,
+                                           "LDE domain exceeds the two-adicity of the modulus");
+    const size_t n = (size_t)1 << log_n, N = (size_t)1 << log_N;
+    // interpolate on trace_offset*w_n^k; the coset shift of the evaluation (Polynomial::scale by
+    // lde_offset, src/univariate/mod.rs:99-113) is fused into the inverse transform's output
+    // scaling, so the forward transform runs with offset 1 and reads the n coefficients from
+    // the head of each output column (zero-padded to N on the fly).
+    SMI_TRY(dev_ntt(ctx, d_cols, d_out, log_n, n, n_cols, n, N, 1, trace_offset, lde_offset));
+    return dev_ntt(ctx, d_out, d_out, log_N, n, n_cols, N, N, 0, 1, 1);
+}
+
+static int host_ntt(smi_ctx *ctx, const uint64_t *in, size_t n_in, uint64_t *out, uint32_t log_n, int inverse, uint64_t offset) {
+    const size_t n = (size_t)1 << log_n;
+    void *stage, *d_in, *d_out;
+    SMI_TRY(ctx_tmp(ctx, 0, n * 8, &stage));
+    SMI_TRY(ctx_tmp(ctx, 1, (n_in ? n_in : 1) * 4, &d_in));
+    SMI_TRY(ctx_tmp(ctx, 2, n * 4, &d_out));
+    if (n_in) {
+        HIP_TRY(ctx, hipMemcpyAsync(stage, in, n_in * 8, hipMemcpyHostToDevice, ctx->stream));
+        SMI_TRY(launch_narrow(ctx, (const uint64_t *)stage, (uint32_t *)d_in, n_in, 0));
+    }
+    SMI_TRY(dev_ntt(ctx, (const uint32_t *)d_in, (uint32_t *)d_out, log_n, n_in, 1, n_in, n, inverse, offset, 1));
+    SMI_TRY(launch_widen(ctx, (const uint32_t *)d_out, (uint64_t *)stage, n));
+    HIP_TRY(ctx, hipMemcpyAsync(out, stage, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    return check_flag(ctx);
+}
+
+int smi_intt(smi_ctx *ctx, const uint64_t *values, uint64_t *coeffs, uint32_t log_n, uint64_t offset) {
+    if (!ctx || !values || !coeffs) return SMI_ERR_BAD_ARG;
+    if (log_n > 40) return SMI_ERR_BAD_ARG;
+    if (offset % ctx->fs.F.p == 0) return smi_fail(ctx, SMI_ERR_NO_INVERSE, "no inverse");  // duplicate domain points, src/ff.rs:171
+    return host_ntt(ctx, values, (size_t)1 << log_n, coeffs, log_n, 1, offset);
+}
+int smi_coset_ntt(smi_ctx *ctx, const uint64_t *coeffs, size_t n_coeffs, uint64_t *evals, uint32_t log_N, uint64_t offset) {
+    if (!ctx || (!coeffs && n_coeffs) || !evals) return SMI_ERR_BAD_ARG;
+    if (log_N > 40 || n_coeffs > ((size_t)1 << log_N)) return SMI_ERR_BAD_ARG;
+    if (offset % ctx->fs.F.p == 0) return smi_fail(ctx, SMI_ERR_BAD_ARG, "coset offset must be nonzero");
+    return host_ntt(ctx, coeffs, n_coeffs, evals, log_N, 0, offset);
+}
+
+// out[i] = coeffs[i] * factor^i -- Polynomial::scale (src/univariate/mod.rs:99-113)
+__global__ void scale_kernel(const uint32_t *in, uint32_t *out, size_t n, Fp F, ScaleTables S) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += step) out[i] = mont_mul(in[i], two_level(S.lo, S.hi, S.h, (uint32_t)i, F), F);
+}
+int smi_poly_scale(smi_ctx *ctx, const uint64_t *coeffs, size_t n, uint64_t factor, uint64_t *out) {
+    if (!ctx || (!coeffs && n) || (!out && n)) return SMI_ERR_BAD_ARG;
+    if (!n) return SMI_OK;
+    if (factor >= ctx->fs.F.p) return smi_fail(ctx, SMI_ERR_NON_CANONICAL, "factor must be < p");
+    uint32_t L = 0;
+    while (((size_t)1 << L) < n) L++;
+    void *stage, *d_in, *d_out;
+    SMI_TRY(ctx_tmp(ctx, 0, n * 8, &stage));
+    SMI_TRY(ctx_tmp(ctx, 1, n * 4, &d_in));
+    SMI_TRY(ctx_tmp(ctx, 2, n * 4, &d_out));
+    ScaleTables S;
+    SMI_TRY(ctx_scale_tables(ctx, 1, (uint32_t)factor, L, &S));
+    HIP_TRY(ctx, hipMemcpyAsync(stage, coeffs, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    SMI_TRY(launch_narrow(ctx, (const uint64_t *)stage, (uint32_t *)d_in, n, 0));
+    size_t grid = (n + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    scale_kernel<<<(uint32_t)grid, 256, 0, ctx->stream>>>((const uint32_t *)d_in, (uint32_t *)d_out, n, ctx->fs.F, S);
+    HIP_TRY(ctx, hipGetLastError());
+    SMI_TRY(launch_widen(ctx, (const uint32_t *)d_out, (uint64_t *)stage, n));
+    HIP_TRY(ctx, hipMemcpyAsync(out, stage, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    return check_flag(ctx);
+}
+
+int smi_lde(smi_ctx *ctx, const uint64_t *cols, uint32_t n_cols, uint32_t log_n, uint32_t log_blowup, uint64_t trace_offset,
+            uint64_t lde_offset, uint64_t *out) {
+    if (!ctx || !cols || !out || !n_cols) return SMI_ERR_BAD_ARG;
+    if (log_n + log_blowup > ctx->fs.K)
+        return smi_fail(ctx, ctx->fs.F.p == 998244353u ? SMI_ERR_ROOT_TOO_LARGE : SMI_ERR_UNSUPPORTED_PRIME, "LDE domain too large");
+    const size_t n = (size_t)1 << log_n, N = n << log_blowup;
+    void *stage, *d_in, *d_out;
+    SMI_TRY(ctx_tmp(ctx, 0, (size_t)n_cols * N * 8, &stage));
+    SMI_TRY(ctx_tmp(ctx, 1, (size_t)n_cols * n * 4, &d_in));
+    SMI_TRY(ctx_tmp(ctx, 2, (size_t)n_cols * N * 4, &d_out));
+    HIP_TRY(ctx, hipMemcpyAsync(stage, cols, (size_t)n_cols * n * 8, hipMemcpyHostToDevice, ctx->stream));
+    SMI_TRY(launch_narrow(ctx, (const uint64_t *)stage, (uint32_t *)d_in, (size_t)n_cols * n, 0));
+    SMI_TRY(smi_dev_lde(ctx, (const uint32_t *)d_in, n_cols, log_n, log_blowup, trace_offset, lde_offset, (uint32_t *)d_out));
+    SMI_TRY(launch_widen(ctx, (const uint32_t *)d_out, (uint64_t *)stage, (size_t)n_cols * N));
+    HIP_TRY(ctx, hipMemcpyAsync(out, stage, (size_t)n_cols * N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    return check_flag(ctx);
+}
+
+// Trace::to_field_elements + get_col (src/trace.rs:21-34): row-major i128 -> column-major u64.
+// `e as u64` keeps the low 64 bits; the device needs canonical residues, so reduce mod p here.
+int smi_trace_pack(const smi_ctx *ctx, const void *rows_i128, size_t n_rows, size_t n_cols, uint64_t *cols_out) {
+    if (!ctx || !rows_i128 || !cols_out) return SMI_ERR_BAD_ARG;
+    const uint64_t *w = (const uint64_t *)rows_i128;  // little-endian i128 = (lo, hi)
+    const uint32_t p = ctx->fs.F.p;
+    for (size_t r = 0; r < n_rows; r++)
+        for (size_t c = 0; c < n_cols; c++) cols_out[c * n_rows + r] = w[2 * (r * n_cols + c)] % p;
+    return SMI_OK;
+}
+
+// ------------------------------------------------------------------------- hash / merkle
+int smi_dev_hash_leaves(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_digests) {
+    if (!ctx || (n && (!d_elems || !d_digests))) return SMI_ERR_BAD_ARG;
+    return launch_leaf_hash(ctx, d_elems, n, d_digests);
+}
+int smi_dev_merkle_build(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_nodes) {
+    if (!ctx || !d_elems || !d_nodes) return SMI_ERR_BAD_ARG;
+    if (n == 0) return smi_fail(ctx, SMI_ERR_EMPTY_LEAVES, nullptr);
+    if (!is_pow2(n)) return smi_fail(ctx, SMI_ERR_LEAVES_NOT_POW2, nullptr);
+    return launch_merkle(ctx, d_elems, n, d_nodes);
+}
+int smi_dev_merkle_from_digests(smi_ctx *ctx, size_t n, uint8_t *d_nodes) {
+    if (!ctx || !d_nodes) return SMI_ERR_BAD_ARG;
+    if (n == 0) return smi_fail(ctx, SMI_ERR_EMPTY_LEAVES, nullptr);
+    if (!is_pow2(n)) return smi_fail(ctx, SMI_ERR_LEAVES_NOT_POW2, nullptr);
+    return launch_merkle(ctx, nullptr, n, d_nodes);
+}
+
+int smi_hash_leaves(smi_ctx *ctx, const uint64_t *elems, size_t n, uint8_t *digests) {
+    if (!ctx || (n && (!elems || !digests))) return SMI_ERR_BAD_ARG;
+    if (!n) return SMI_OK;
+    void *stage, *d_in, *d_out;
+    SMI_TRY(ctx_tmp(ctx, 0, n * 8, &stage));
+    SMI_TRY(ctx_tmp(ctx, 1, n * 4, &d_in));
+    SMI_TRY(ctx_tmp(ctx, 2, n * 32, &d_out));
+    HIP_TRY(ctx, hipMemcpyAsync(stage, elems, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    SMI_TRY(launch_narrow(ctx, (const uint64_t *)stage, (uint32_t *)d_in, n, 0));
+    SMI_TRY(launch_leaf_hash(ctx, (const uint32_t *)d_in, n, (uint8_t *)d_out));
+    HIP_TRY(ctx, hipMemcpyAsync(digests, d_out, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    return check_flag(ctx);
+}
+int smi_hash_combine_pairs(smi_ctx *ctx, const uint8_t *digests, size_t n_pairs, uint8_t *out) {
+    if (!ctx || (n_pairs && (!digests || !out))) return SMI_ERR_BAD_ARG;
+    if (!n_pairs) return SMI_OK;
+    void *d_in, *d_out;
+    SMI_TRY(ctx_tmp(ctx, 1, n_pairs * 64, &d_in));
+    SMI_TRY(ctx_tmp(ctx, 2, n_pairs * 32, &d_out));
+    HIP_TRY(ctx, hipMemcpyAsync(d_in, digests, n_pairs * 64, hipMemcpyHostToDevice, ctx->stream));
+    SMI_TRY(launch_combine(ctx, (const uint8_t *)d_in, n_pairs, (uint8_t *)d_out));
+    HIP_TRY(ctx, hipMemcpyAsync(out, d_out, n_pairs * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SMI_OK;
+}
+int smi_hash_bytes(smi_ctx *ctx, const uint8_t *msg, size_t len, uint8_t out[32]) {
+    if (!ctx || (len && !msg) || !out) return SMI_ERR_BAD_ARG;
+    void *d_in, *d_out;
+    SMI_TRY(ctx_tmp(ctx, 1, len + 4, &d_in));
+    SMI_TRY(ctx_tmp(ctx, 2, 32, &d_out));
+    if (len) HIP_TRY(ctx, hipMemcpyAsync(d_in, msg, len, hipMemcpyHostToDevice, ctx->stream));
+    SMI_TRY(launch_hash_bytes(ctx, (const uint8_t *)d_in, len, (uint32_t *)d_out));
+    HIP_TRY(ctx, hipMemcpyAsync(out, d_out, 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SMI_OK;
+}
+
+static int tree_alloc(smi_ctx *ctx, size_t n, smi_tree **out) {
+    if (n == 0) return smi_fail(ctx, SMI_ERR_EMPTY_LEAVES, nullptr);        // src/merkle.rs:12
+    if (!is_pow2(n)) return smi_fail(ctx, SMI_ERR_LEAVES_NOT_POW2, nullptr);  // src/merkle.rs:13-16
+    smi_tree *t = new smi_tree{ctx, nullptr, n, true};
+    if (hipMalloc((void **)&t->d_nodes, (2 * n - 1) * 32) != hipSuccess) {
+        delete t;
+        return smi_fail(ctx, SMI_ERR_OOM, "hipMalloc tree");
+    }
+    *out = t;
+    return SMI_OK;
+}
+int smi_merkle_new(smi_ctx *ctx, const uint8_t *leaves, size_t n, smi_tree **out) {
+    if (!ctx || !out || (n && !leaves)) return SMI_ERR_BAD_ARG;
+    smi_tree *t = nullptr;
+    SMI_TRY(tree_alloc(ctx, n, &t));
+    int rc = SMI_OK;
+    if (hipMemcpyAsync(t->d_nodes, leaves, n * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = smi_fail(ctx, SMI_ERR_HIP, "upload leaves");
+    if (rc == SMI_OK) rc = launch_merkle(ctx, nullptr, n, t->d_nodes);
+    if (rc == SMI_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = smi_fail(ctx, SMI_ERR_HIP, "merkle sync");
+    if (rc != SMI_OK) {
+        smi_merkle_free(t);
+        return rc;
+    }
+    *out = t;
+    return SMI_OK;
+}
+int smi_merkle_from_codeword(smi_ctx *ctx, const uint64_t *codeword, size_t n, smi_tree **out) {
+    if (!ctx || !out || (n && !codeword)) return SMI_ERR_BAD_ARG;
+    smi_tree *t = nullptr;
+    SMI_TRY(tree_alloc(ctx, n, &t));
+    void *stage, *d_in;
+    int rc = ctx_tmp(ctx, 0, n * 8, &stage);
+    if (rc == SMI_OK) rc = ctx_tmp(ctx, 1, n * 4, &d_in);
+    if (rc == SMI_OK && hipMemcpyAsync(stage, codeword, n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = smi_fail(ctx, SMI_ERR_HIP, "upload codeword");
+    if (rc == SMI_OK) rc = launch_narrow(ctx, (const uint64_t *)stage, (uint32_t *)d_in, n, 0);
+    if (rc == SMI_OK) rc = launch_merkle(ctx, (const uint32_t *)d_in, n, t->d_nodes);
+    if (rc == SMI_OK) rc = check_flag(ctx);
+    if (rc != SMI_OK) {
+        smi_merkle_free(t);
+        return rc;
+    }
+    *out = t;
+    return SMI_OK;
+}
+int smi_merkle_commit(smi_ctx *ctx, const uint8_t *leaves, size_t n, uint8_t root[32]) {
+    if (!ctx || !root) return SMI_ERR_BAD_ARG;
+    smi_tree *t = nullptr;
+    SMI_TRY(smi_merkle_new(ctx, leaves, n, &t));
+    int rc = smi_merkle_root(ctx, t, root);
+    smi_merkle_free(t);
+    return rc;
+}
+int smi_merkle_root(smi_ctx *ctx, const smi_tree *t, uint8_t root[32]) {
+    if (!ctx || !t || !root) return SMI_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipMemcpyAsync(root, t->d_nodes + (2 * t->n - 2) * 32, 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SMI_OK;
+}
+int smi_merkle_open(smi_ctx *ctx, const smi_tree *t, size_t index, uint8_t *path, size_t *depth) {
+    if (!ctx || !t || !path || !depth) return SMI_ERR_BAD_ARG;
+    if (index >= t->n) return smi_fail(ctx, SMI_ERR_INDEX_OOB, nullptr);  // src/merkle.rs:68
+    size_t idx = index, off = 0, len = t->n, d = 0;
+    while (len > 1) {  // sibling at each level (src/merkle.rs:73-77)
+        HIP_TRY(ctx, hipMemcpyAsync(path + 32 * d, t->d_nodes + (off + (idx ^ 1)) * 32, 32, hipMemcpyDeviceToHost, ctx->stream));
+        idx >>= 1;
+        off += len;
+        len >>= 1;
+        d++;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *depth = d;
+    return SMI_OK;
+}
+int smi_merkle_level(smi_ctx *ctx, const smi_tree *t, uint32_t level, uint8_t *out, size_t *n_out) {
+    if (!ctx || !t || !out) return SMI_ERR_BAD_ARG;
+    if (level > ilog2(t->n)) return smi_fail(ctx, SMI_ERR_INDEX_OOB, nullptr);
+    const size_t cnt = t->n >> level, off = 2 * t->n - ((2 * t->n) >> level);
+    HIP_TRY(ctx, hipMemcpyAsync(out, t->d_nodes + off * 32, cnt * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_out) *n_out = cnt;
+    return SMI_OK;
+}
+size_t smi_merkle_num_leaves(const smi_tree *t) { return t ? t->n : 0; }
+void smi_merkle_free(smi_tree *t) {
+    if (!t) return;
+    if (t->ctx && t->ctx->stream) (void)hipStreamSynchronize(t->ctx->stream);
+    if (t->owns) (void)hipFree(t->d_nodes);
+    delete t;
+}
+void smi_free(void *p) { free(p); }
+
+// ------------------------------------------------------------------------- four-step pieces
+// See fourstep.hip

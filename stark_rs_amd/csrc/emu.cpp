@@ -1,0 +1,119 @@
+// emu.cpp -- CPU emulator of the NTT kernels' thread phases (TEST INFRASTRUCTURE).
+//
+// The build container has no GPU, so the non-GPU tests run the very same phase functions
+// (ntt_core.h) and pass sequencing (ntt_driver.h) the HIP kernels use, one "thread" at a
+// time, and compare with the oracle.  This catches indexing / twiddle / planning mistakes
+// before GPU time is spent.  The product never loads this library: stark_rs_amd fails
+// loudly without libstarkmi.so and a GPU.
+#include <vector>
+
+#include "ntt_driver.h"
+#include "tables.h"
+
+namespace {
+
+std::vector<uint32_t> fill(const GeomSpec &s, const Fp &F) {
+    std::vector<uint32_t> t(s.count);
+    for (uint32_t i = 0; i < s.count; i++) t[i] = geom_entry(s.c_m, s.q_m, i, s.stride, F);
+    return t;
+}
+
+template <int LOGR, bool LAST> void emu_pass(const PassArgs &a, uint32_t batch) {
+    typedef NttPass<LOGR, LAST> NP;
+    std::vector<uint32_t> tile(NP::R * NP::WP), tw(NP::R);
+    for (uint32_t b = 0; b < batch; b++)
+        for (uint32_t blk = 0; blk < a.n_tiles; blk++) {
+            typename NP::TileId t = NP::tile_id(a, blk);
+            for (uint32_t tid = 0; tid < SMI_NTT_THREADS; tid++) NP::load_tw(a, tw.data(), tid);
+            for (uint32_t tid = 0; tid < SMI_NTT_THREADS; tid++) NP::load(a, t, b, tile.data(), tid);
+            for (uint32_t tid = 0; tid < SMI_NTT_THREADS; tid++) NP::template step_i<0>(a, tile.data(), tw.data(), tid);
+            for (uint32_t tid = 0; tid < SMI_NTT_THREADS; tid++) NP::template step_i<1>(a, tile.data(), tw.data(), tid);
+            for (uint32_t tid = 0; tid < SMI_NTT_THREADS; tid++) NP::template step_i<2>(a, tile.data(), tw.data(), tid);
+            for (uint32_t tid = 0; tid < SMI_NTT_THREADS; tid++) NP::store(a, t, b, tile.data(), tid);
+        }
+}
+
+struct EmuLauncher {
+    void small(const SmallArgs &a, uint32_t batch) {
+        std::vector<uint32_t> buf(1u << a.L);
+        for (uint32_t b = 0; b < batch; b++) {
+            for (uint32_t tid = 0; tid < SMI_NTT_THREADS; tid++) NttSmall::load(a, b, buf.data(), tid);
+            for (uint32_t s = 0; s < a.L; s++)
+                for (uint32_t tid = 0; tid < SMI_NTT_THREADS; tid++) NttSmall::stage(a, s, buf.data(), tid);
+            for (uint32_t tid = 0; tid < SMI_NTT_THREADS; tid++) NttSmall::store(a, b, buf.data(), tid);
+        }
+    }
+    void pass(int logr, bool last, const PassArgs &a, uint32_t batch) {
+#define CASE(LR)                                                   \
+    case LR:                                                       \
+        if (last) emu_pass<LR, true>(a, batch);                    \
+        else emu_pass<LR, false>(a, batch);                        \
+        break;
+        switch (logr) { CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) }
+#undef CASE
+    }
+};
+
+}  // namespace
+
+extern "C" int emu_ntt(uint64_t p, uint64_t g, const uint32_t *in, uint32_t *out, uint32_t L, uint32_t n_in,
+                       uint32_t batch, uint64_t in_stride, uint64_t out_stride, int inverse, uint64_t offset,
+                       uint64_t post_scale) {
+    FieldSetup fs;
+    if (!field_setup(p, g, &fs) || L > fs.K) return -1;
+    const Fp &F = fs.F;
+    GeomSpec sp[3];
+    ntt_table_specs(fs, inverse, sp);
+    std::vector<uint32_t> tw10 = fill(sp[0], F), lo = fill(sp[1], F), hi = fill(sp[2], F);
+    NttRequest rq;
+    memset(&rq, 0, sizeof rq);
+    rq.T = NttTables{tw10.data(), lo.data(), hi.data(), fs.K, ntt_table_h(fs.K)};
+    std::vector<uint32_t> slo, shi;
+    const uint32_t pp = F.p;
+    if (!inverse) {
+        rq.pre_scale = offset % pp != 1;
+        if (rq.pre_scale) {
+            GeomSpec s2[2];
+            scale_table_specs(F, 1, (uint32_t)(offset % pp), L, s2);
+            slo = fill(s2[0], F); shi = fill(s2[1], F);
+        }
+    } else {
+        rq.post_scale = true;
+        const uint32_t ninv = host_powmod((uint32_t)((1ull << L) % pp), pp - 2, pp);
+        const uint32_t q = host_mulmod((uint32_t)(post_scale % pp), host_powmod((uint32_t)(offset % pp), pp - 2, pp), pp);
+        GeomSpec s2[2];
+        scale_table_specs(F, ninv, q, L, s2);
+        slo = fill(s2[0], F); shi = fill(s2[1], F);
+    }
+    rq.S = ScaleTables{slo.data(), shi.data(), scale_table_h(L)};
+    std::vector<uint32_t> scratch((size_t)batch << L);
+    rq.in = in; rq.out = out; rq.scratch = scratch.data();
+    rq.L = L; rq.n_in = n_in; rq.batch = batch; rq.in_stride = in_stride; rq.out_stride = out_stride; rq.F = F;
+    EmuLauncher ln;
+    ntt_run(ln, rq);
+    return 0;
+}
+
+// ---- hash phases (hash_core.h) --------------------------------------------------------
+#include "hash_core.h"
+extern "C" void emu_leaf_hash(const uint32_t *v, size_t n, uint8_t *out) {
+    for (size_t i = 0; i < n; i++) {
+        uint32_t d[8];
+        hashc::leaf_hash(v[i], d);
+        memcpy(out + 32 * i, d, 32);
+    }
+}
+extern "C" void emu_node_hash(const uint8_t *pairs, size_t n, uint8_t *out) {
+    for (size_t i = 0; i < n; i++) {
+        uint32_t l[8], r[8], d[8];
+        memcpy(l, pairs + 64 * i, 32);
+        memcpy(r, pairs + 64 * i + 32, 32);
+        hashc::node_hash(l, r, d);
+        memcpy(out + 32 * i, d, 32);
+    }
+}
+extern "C" void emu_hash_bytes(const uint8_t *msg, size_t len, uint8_t *out) {
+    uint32_t d[8];
+    hashc::hash_bytes(msg, len, d);
+    memcpy(out, d, 32);
+}

@@ -1,0 +1,85 @@
+// field.h -- prime-field arithmetic for p < 2^31, u32 storage.
+//
+// Device counterpart of FiniteField::{add,sub,mul,neg} (reference src/ff.rs:138-167).
+// The reference widens to u128 and takes `% p`; every result is the canonical residue
+// in [0,p), so any exact modular arithmetic is bit-identical.  Here: conditional-subtract
+// add/sub and a 32x32->64 Montgomery product (R = 2^32).  Twiddles are stored in
+// Montgomery form (w*R mod p) so mont_mul(x, wR) = x*w mod p keeps data in plain form.
+//
+// Functions are host+device so the index/arith logic can also be exercised by the
+// host-side emulator used in CPU tests (no GPU in the build container).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SMI_HD __host__ __device__ __forceinline__
+#else
+#define SMI_HD inline
+#endif
+
+struct Fp {
+    uint32_t p;     // modulus, odd, < 2^31
+    uint32_t pinv;  // p^-1 mod 2^32
+    uint32_t r1;    // R mod p      (Montgomery form of 1)
+    uint32_t r2;    // R^2 mod p    (to_mont(x) = mont_mul(x, r2))
+};
+
+SMI_HD uint32_t fp_add(uint32_t a, uint32_t b, uint32_t p) {
+    uint32_t s = a + b;  // a,b < p < 2^31: no wrap
+    return s >= p ? s - p : s;
+}
+SMI_HD uint32_t fp_sub(uint32_t a, uint32_t b, uint32_t p) {
+    uint32_t d = a - b;
+    return a < b ? d + p : d;
+}
+SMI_HD uint32_t fp_neg(uint32_t a, uint32_t p) { return a ? p - a : 0; }
+
+// a*b*R^-1 mod p for a*b < p*2^32 (e.g. a < p, b arbitrary u32).  Result in [0,p).
+SMI_HD uint32_t mont_mul(uint32_t a, uint32_t b, const Fp &F) {
+    uint64_t t = (uint64_t)a * b;
+    uint32_t m = (uint32_t)t * F.pinv;
+    uint32_t u = (uint32_t)(((uint64_t)m * F.p) >> 32);
+    uint32_t hi = (uint32_t)(t >> 32);
+    uint32_t r = hi - u;           // low words of t and m*p are equal: no borrow from below
+    return hi < u ? r + F.p : r;
+}
+SMI_HD uint32_t to_mont(uint32_t a, const Fp &F) { return mont_mul(a, F.r2, F); }
+SMI_HD uint32_t from_mont(uint32_t a, const Fp &F) { return mont_mul(a, 1u, F); }
+
+// base^e with base in Montgomery form; result in Montgomery form.
+SMI_HD uint32_t mont_pow(uint32_t base_m, uint64_t e, const Fp &F) {
+    uint32_t res = F.r1;
+    while (e) {
+        if (e & 1) res = mont_mul(res, base_m, F);
+        base_m = mont_mul(base_m, base_m, F);
+        e >>= 1;
+    }
+    return res;
+}
+
+// Reduce an arbitrary u64 (e.g. an unreduced Fiat-Shamir challenge, reference
+// src/fiat_shamir.rs:23-24) to [0,p).
+SMI_HD uint32_t reduce_u64(uint64_t v, uint32_t p) { return (uint32_t)(v % p); }
+
+// ---- host-only helpers -------------------------------------------------------------
+inline uint32_t host_mulmod(uint32_t a, uint32_t b, uint32_t p) { return (uint32_t)(((uint64_t)a * b) % p); }
+inline uint32_t host_powmod(uint32_t b, uint64_t e, uint32_t p) {
+    uint32_t r = 1 % p;
+    while (e) {
+        if (e & 1) r = host_mulmod(r, b, p);
+        b = host_mulmod(b, b, p);
+        e >>= 1;
+    }
+    return r;
+}
+inline Fp fp_make(uint32_t p) {
+    Fp F;
+    F.p = p;
+    uint32_t inv = p;  // Newton: inv*p == 1 mod 2^32 (p odd; 3 correct bits to start)
+    for (int i = 0; i < 5; i++) inv *= 2u - p * inv;
+    F.pinv = inv;
+    F.r1 = (uint32_t)((1ull << 32) % p);
+    F.r2 = (uint32_t)(((uint64_t)F.r1 * F.r1) % p);
+    return F;
+}

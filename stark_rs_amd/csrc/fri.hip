@@ -1,0 +1,479 @@
+// fri.hip -- FRI fold kernel, on-device Fiat-Shamir / index sampling, query gather, and
+// the host orchestration of Fri::commit / Fri::prove (reference src/fri.rs:57-311).
+//
+// The round loop of src/fri.rs:116-148 has a serial dependency root -> alpha -> fold
+// (SURVEY H5).  Here the transcript state lives on the device: a single-lane kernel absorbs
+// each root and draws alpha into device memory, the fold kernel reads alpha from there, so
+// a whole prove is enqueued without one host round trip; the host synchronises once to
+// copy the serialized proof back.
+#include "hash_core.h"
+#include "internal.h"
+
+int launch_merkle(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_nodes);
+
+// ------------------------------------------------------------------------- fold
+// out[i] = 2^-1 * ((1 + a/x_i) c[i] + (1 - a/x_i) c[i+h])            (src/fri.rs:70-88)
+//        = 2^-1 (c[i] + c[i+h]) + (a * 2^-1 * x_i^-1) (c[i] - c[i+h]),  x_i = offset * omega^i
+// x_i^-1 comes from the two-level table S = offset^-1 * omega^-i; alpha is read from device
+// memory (unreduced u64, src/fiat_shamir.rs:23-24) and reduced here.  HBM-bound: 12 B in,
+// 4 B out per output element.
+__global__ __launch_bounds__(256) void fri_fold_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                       uint32_t half, const uint64_t *__restrict__ alpha_ptr, Fp F,
+                                                       ScaleTables S, uint32_t inv2_m) {
+    const uint32_t a = (uint32_t)(*alpha_ptr % F.p);
+    const uint32_t ah_m = mont_mul(to_mont(a, F), inv2_m, F);  // (alpha/2) in Montgomery form
+    const uint32_t step = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < half; i += step) {
+        const uint32_t x = in[i], y = in[i + half];
+        const uint32_t s = fp_add(x, y, F.p), d = fp_sub(x, y, F.p);
+        const uint32_t t_m = mont_mul(two_level(S.lo, S.hi, S.h, i, F), ah_m, F);
+        out[i] = fp_add(mont_mul(s, inv2_m, F), mont_mul(d, t_m, F), F.p);
+    }
+}
+
+// ------------------------------------------------------------------------- Fiat-Shamir
+// FiatShamir::{absorb,challenge} (src/fiat_shamir.rs:15-25).  Only whole 32-byte roots are
+// ever absorbed (src/fri.rs:131), so the sponge state after k roots is carried in
+// fs_state (16 words) and `challenge` = 8 more mixes on a copy: the same function of the
+// whole transcript as re-hashing it, evaluated incrementally.
+struct FsState {
+    uint32_t s[16];
+};
+
+__global__ void fs_init_kernel(FsState *fs) {
+    if (threadIdx.x || blockIdx.x) return;
+    hashc::State st;
+    hashc::init(st);
+    for (int i = 0; i < 16; i++) fs->s[i] = st.s[i];
+}
+
+// absorb the root at `root`, append it (tag 0 + 32 bytes, src/stream.rs:39-42) to the proof
+// buffer, and if alpha_out != nullptr draw the challenge.
+__global__ void fs_round_kernel(FsState *fs, const uint32_t *root, uint8_t *proof_slot, uint64_t *alpha_out) {
+    if (threadIdx.x || blockIdx.x) return;
+    hashc::State st;
+    for (int i = 0; i < 16; i++) st.s[i] = fs->s[i];
+    uint32_t m[8];
+    for (int i = 0; i < 8; i++) m[i] = root[i];
+    hashc::absorb_chunk32(st, m);
+    for (int i = 0; i < 16; i++) fs->s[i] = st.s[i];
+    if (proof_slot) {
+        proof_slot[0] = 0;
+        for (int i = 0; i < 32; i++) proof_slot[1 + i] = (uint8_t)(m[i >> 2] >> (8 * (i & 3)));
+    }
+    if (alpha_out) {
+        for (int k = 0; k < 8; k++) hashc::mix(st);
+        uint32_t d[8];
+        hashc::to_words(st, d);
+        *alpha_out = (uint64_t)d[0] | ((uint64_t)d[1] << 32);
+    }
+}
+
+// challenge without absorbing (src/fri.rs:272: the index-sampling seed)
+__global__ void fs_challenge_kernel(const FsState *fs, uint64_t *alpha_out) {
+    if (threadIdx.x || blockIdx.x) return;
+    hashc::State st;
+    for (int i = 0; i < 16; i++) st.s[i] = fs->s[i];
+    for (int k = 0; k < 8; k++) hashc::mix(st);
+    uint32_t d[8];
+    hashc::to_words(st, d);
+    *alpha_out = (uint64_t)d[0] | ((uint64_t)d[1] << 32);
+}
+
+// Fri::sample_indices (src/fri.rs:176-213) with seed = Hash::from_u64(challenge).0
+// (src/fri.rs:272, src/hash.rs:37-39).  Single lane; `number` <= reduced_size is checked on
+// the host.  indices[0..number) = accepted (unreduced) indices; reduced[] is workspace.
+__global__ void sample_indices_kernel(const uint64_t *challenge, uint64_t size, uint64_t reduced_size, uint32_t number,
+                                      uint64_t *indices, uint64_t *reduced) {
+    if (threadIdx.x || blockIdx.x) return;
+    // seed = hash of the 8 LE bytes of the (unreduced) challenge
+    const uint64_t ch = *challenge;
+    hashc::State st;
+    hashc::init(st);
+#pragma unroll
+    for (int i = 0; i < 8; i++) hashc::absorb_byte(st, i, (uint32_t)(ch >> (8 * i)) & 0xFFu);
+    hashc::mix(st);
+    for (int k = 0; k < 8; k++) hashc::mix(st);
+    uint32_t seed[8];
+    hashc::to_words(st, seed);
+    // state after the first chunk (= seed) of every seed||counter message
+    hashc::State base;
+    hashc::init(base);
+    hashc::absorb_chunk32(base, seed);
+    uint32_t cnt = 0, counter = 0;
+    while (cnt < number) {
+        hashc::State s2 = base;
+#pragma unroll
+        for (int i = 0; i < 4; i++) hashc::absorb_byte(s2, i, (counter >> (8 * i)) & 0xFFu);
+        hashc::mix(s2);
+        for (int k = 0; k < 8; k++) hashc::mix(s2);
+        uint32_t d[8];
+        hashc::to_words(s2, d);
+        // sample_index (src/fri.rs:168-174): u128 shift-xor over 32 bytes, truncated to usize
+        // = the last 8 digest bytes read big-endian
+        uint64_t acc = 0;
+#pragma unroll
+        for (int i = 24; i < 32; i++) acc = (acc << 8) | ((d[i >> 2] >> (8 * (i & 3))) & 0xFFu);
+        const uint64_t index = acc % size, ri = index % reduced_size;
+        counter++;
+        bool seen = false;
+        for (uint32_t k = 0; k < cnt; k++) seen |= reduced[k] == ri;
+        if (!seen) {
+            indices[cnt] = index;
+            reduced[cnt] = ri;
+            cnt++;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------- query gather
+// Fri::query (src/fri.rs:215-248) for every layer, written straight into the serialized
+// ProofStream layout (src/stream.rs:35-64).  One workgroup per (layer, test).
+struct LayerInfo {
+    const uint32_t *cw, *cw_next;
+    const uint8_t *nodes, *nodes_next;
+    uint64_t len;           // of cw
+    uint64_t off_triples;   // byte offset of this layer's first FieldElements triple
+    uint64_t off_paths;     // byte offset of this layer's first MerklePath
+    uint32_t depth, depth_next;
+};
+
+__device__ void put_u64(uint8_t *p, uint64_t v) {
+    for (int i = 0; i < 8; i++) p[i] = (uint8_t)(v >> (8 * i));
+}
+// MerkleTree::open (src/merkle.rs:67-80) serialized as tag 3, u64 count, 32 B digests
+__device__ void write_path(uint8_t *dst, const uint8_t *nodes, uint64_t n, uint32_t depth, uint64_t index, uint32_t lane) {
+    if (lane == 0) {
+        dst[0] = 3;
+        put_u64(dst + 1, depth);
+    }
+    uint64_t idx = index, lvl_off = 0, len = n;
+    for (uint32_t l = 0; l < depth; l++) {
+        const uint64_t sib = idx ^ 1;
+        if (lane < 32) dst[9 + 32 * l + lane] = nodes[(lvl_off + sib) * 32 + lane];
+        idx >>= 1;
+        lvl_off += len;
+        len >>= 1;
+    }
+}
+__global__ void query_kernel(const LayerInfo *layers, const uint64_t *top, uint32_t t, uint8_t *proof) {
+    const LayerInfo L = layers[blockIdx.y];
+    const uint32_t s = blockIdx.x, lane = threadIdx.x;
+    const uint64_t half = L.len / 2;
+    const uint64_t c = top[s] % half;   // indices folded layer by layer: (x % a) % b == x % b for b | a
+    if (lane == 0) {
+        uint8_t *tr = proof + L.off_triples + (uint64_t)s * 33;
+        tr[0] = 2;
+        put_u64(tr + 1, 3);
+        put_u64(tr + 9, L.cw[c]);
+        put_u64(tr + 17, L.cw[c + half]);
+        put_u64(tr + 25, L.cw_next[c]);
+    }
+    const uint64_t pa = 9 + 32ull * L.depth, pc = 9 + 32ull * L.depth_next;
+    uint8_t *pp = proof + L.off_paths + (uint64_t)s * (2 * pa + pc);
+    write_path(pp, L.nodes, L.len, L.depth, c, lane);
+    write_path(pp + pa, L.nodes, L.len, L.depth, c + half, lane);
+    write_path(pp + 2 * pa, L.nodes_next, half, L.depth_next, c, lane);
+}
+
+// last codeword in the clear: tag 2, u64 len, len x u64 (src/fri.rs:151, src/stream.rs:48-53)
+__global__ void emit_codeword_kernel(const uint32_t *cw, uint64_t len, uint8_t *dst) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        dst[0] = 2;
+        put_u64(dst + 1, len);
+    }
+    if (i < len) put_u64(dst + 9 + 8 * i, cw[i]);
+}
+
+// ------------------------------------------------------------------------- host side
+int smi_fri_num_rounds(const smi_fri_cfg *cfg, uint64_t *rounds) {
+    if (!cfg || !rounds) return SMI_ERR_BAD_ARG;
+    uint64_t len = cfg->domain_length, r = 0;  // src/fri.rs:93-103
+    while (len > cfg->expansion_factor && 4 * cfg->num_colinearity_tests < len) {
+        len /= 2;
+        r++;
+    }
+    *rounds = r;
+    return SMI_OK;
+}
+
+static bool is_pow2(uint64_t n) { return n && !(n & (n - 1)); }
+static uint32_t ilog2(uint64_t n) {
+    uint32_t l = 0;
+    while ((n >> l) > 1) l++;
+    return l;
+}
+
+int smi_fri_check(const smi_ctx *ctx, const smi_fri_cfg *cfg) {
+    if (!ctx || !cfg) return SMI_ERR_BAD_ARG;
+    if (!is_pow2(cfg->domain_length)) return SMI_ERR_DOMAIN_NOT_POW2;      // src/fri.rs:37-40
+    if (!is_pow2(cfg->expansion_factor)) return SMI_ERR_EXPANSION_NOT_POW2;  // src/fri.rs:41-44
+    if (cfg->expansion_factor < 4) return SMI_ERR_EXPANSION_TOO_SMALL;       // src/fri.rs:45
+    return SMI_OK;
+}
+
+struct smi_fri_run {
+    smi_ctx *ctx;
+    std::vector<uint32_t *> codewords;  // device, lengths N, N/2, ...
+    std::vector<uint8_t *> trees;       // device nodes per codeword
+    std::vector<uint64_t> lens;
+    void *d_misc;                       // fs state, alphas, indices, layer table
+    uint8_t *d_proof;
+    bool owns_first;                    // codewords[0] allocated by us (vs caller's buffer)
+};
+
+void smi_fri_run_free(smi_fri_run *run) {
+    if (!run) return;
+    hipStreamSynchronize(run->ctx->stream);
+    for (size_t i = 0; i < run->codewords.size(); i++)
+        if (i > 0 || run->owns_first) hipFree(run->codewords[i]);
+    for (uint8_t *t : run->trees) hipFree(t);
+    hipFree(run->d_misc);
+    hipFree(run->d_proof);
+    delete run;
+}
+
+int launch_fold(smi_ctx *ctx, const uint32_t *d_in, size_t len, const uint64_t *d_alpha, uint64_t offset, uint64_t omega,
+                uint32_t *d_out) {
+    const uint32_t p = ctx->fs.F.p;
+    if (len < 2 || !is_pow2(len)) return smi_fail(ctx, SMI_ERR_BAD_ARG, "fold: codeword length must be a power of two >= 2");
+    if (offset >= p || omega >= p) return smi_fail(ctx, SMI_ERR_NON_CANONICAL, "fold: offset/omega must be < p");
+    if (offset == 0 || omega == 0) return smi_fail(ctx, SMI_ERR_DIV_BY_ZERO, "no division by zero");  // src/ff.rs:182
+    const uint32_t half = (uint32_t)(len / 2);
+    ScaleTables S;
+    SMI_TRY(ctx_scale_tables(ctx, h_inv(ctx, (uint32_t)offset), h_inv(ctx, (uint32_t)omega), ilog2(half), &S));
+    const uint32_t inv2_m = (uint32_t)(((uint64_t)h_inv(ctx, 2) << 32) % p);
+    uint32_t grid = (half + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    fri_fold_kernel<<<grid, 256, 0, ctx->stream>>>(d_in, d_out, half, d_alpha, ctx->fs.F, S, inv2_m);
+    HIP_TRY(ctx, hipGetLastError());
+    return SMI_OK;
+}
+
+// misc device block layout
+struct MiscLayout {
+    size_t fs, alphas, seed_ch, top, reduced, layers, total;
+};
+static MiscLayout misc_layout(uint64_t R, uint64_t t) {
+    MiscLayout m;
+    size_t o = 0;
+    m.fs = o; o += sizeof(FsState);
+    o = (o + 63) & ~(size_t)63;
+    m.alphas = o; o += 8 * (R + 1);
+    m.seed_ch = o; o += 8;
+    m.top = o; o += 8 * (t + 1);
+    m.reduced = o; o += 8 * (t + 1);
+    o = (o + 63) & ~(size_t)63;
+    m.layers = o; o += sizeof(LayerInfo) * (R + 1);
+    m.total = o;
+    return m;
+}
+
+// Fri::commit (+ optionally the query phase of Fri::prove) over a device codeword.
+// With do_query == false only roots/alphas/last codeword are produced.
+static int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, size_t len, bool do_query,
+                   smi_fri_run **run_out, std::vector<uint8_t> *proof_host, uint64_t *top_host, uint8_t *roots_host,
+                   uint64_t *alphas_host, uint64_t *last_host, size_t *last_len) {
+    SMI_TRY(smi_fri_check(ctx, cfg));
+    if (cfg->domain_length != len) return smi_fail(ctx, SMI_ERR_CODEWORD_LEN, "initial codeword length does not match domain length");
+    const uint32_t p = ctx->fs.F.p;
+    if (cfg->omega >= p || cfg->offset >= p) return smi_fail(ctx, SMI_ERR_NON_CANONICAL, "omega/offset must be < p");
+    uint64_t R;
+    smi_fri_num_rounds(cfg, &R);
+    if (R == 0) return smi_fail(ctx, SMI_ERR_NO_ROUNDS, "num_rounds() == 0: the reference's verify rejects such a proof");
+    const uint64_t t = cfg->num_colinearity_tests;
+    const uint64_t last_n = len >> (R - 1);
+    if (do_query) {  // asserts of src/fri.rs:183-192
+        if (t > 2 * last_n) return smi_fail(ctx, SMI_ERR_SAMPLE_ENTROPY, "not enough entropy in indices wrt last codeword");
+        if (t > last_n) return smi_fail(ctx, SMI_ERR_SAMPLE_TOO_MANY, "cannot sample more indices than available in last codeword");
+    }
+
+    smi_fri_run *run = new smi_fri_run();
+    run->ctx = ctx;
+    run->owns_first = false;
+    run->d_misc = nullptr;
+    run->d_proof = nullptr;
+    int rc = SMI_OK;
+    auto bail = [&](int code) {
+        smi_fri_run_free(run);
+        return code;
+    };
+
+    // proof layout (src/fri.rs:129,151,229-243; tags src/stream.rs:39-60)
+    const size_t off_roots = 0, off_last = 33 * R, off_layers = off_last + 9 + 8 * last_n;
+    std::vector<LayerInfo> layers(R ? R - 1 : 0);
+    size_t off = off_layers;
+    for (uint64_t i = 0; i + 1 < R; i++) {
+        const uint64_t li = len >> i;
+        const uint32_t d = ilog2(li);
+        layers[i].len = li;
+        layers[i].depth = d;
+        layers[i].depth_next = d - 1;
+        layers[i].off_triples = off;
+        off += 33 * t;
+        layers[i].off_paths = off;
+        off += t * (2 * (9 + 32ull * d) + (9 + 32ull * (d - 1)));
+    }
+    const size_t proof_len = do_query ? off : off_layers;
+
+    const MiscLayout ml = misc_layout(R, t);
+    if (hipMalloc(&run->d_misc, ml.total) != hipSuccess) return bail(smi_fail(ctx, SMI_ERR_OOM, "hipMalloc misc"));
+    if (hipMalloc((void **)&run->d_proof, proof_len) != hipSuccess) return bail(smi_fail(ctx, SMI_ERR_OOM, "hipMalloc proof"));
+    uint8_t *misc = (uint8_t *)run->d_misc;
+    FsState *d_fs = (FsState *)(misc + ml.fs);
+    uint64_t *d_alphas = (uint64_t *)(misc + ml.alphas);
+    uint64_t *d_seed_ch = (uint64_t *)(misc + ml.seed_ch);
+    uint64_t *d_top = (uint64_t *)(misc + ml.top);
+    uint64_t *d_reduced = (uint64_t *)(misc + ml.reduced);
+    LayerInfo *d_layers = (LayerInfo *)(misc + ml.layers);
+
+    fs_init_kernel<<<1, 64, 0, ctx->stream>>>(d_fs);
+
+    uint32_t omega = (uint32_t)cfg->omega, offset = (uint32_t)cfg->offset;
+    const uint32_t *cur = d_codeword;
+    uint64_t cur_len = len;
+    for (uint64_t r = 0; r < R; r++) {
+        // leaf hashes + tree (src/fri.rs:118-127); power-of-two lengths never need padding
+        uint8_t *nodes = nullptr;
+        if (hipMalloc((void **)&nodes, (2 * cur_len - 1) * 32) != hipSuccess) return bail(smi_fail(ctx, SMI_ERR_OOM, "hipMalloc tree"));
+        run->trees.push_back(nodes);
+        run->codewords.push_back(const_cast<uint32_t *>(cur));
+        run->lens.push_back(cur_len);
+        if ((rc = launch_merkle(ctx, cur, cur_len, nodes)) != SMI_OK) return bail(rc);
+        const uint32_t *root = (const uint32_t *)(nodes + (2 * cur_len - 2) * 32);
+        const bool last = r == R - 1;
+        // push root, absorb, challenge (src/fri.rs:129-138)
+        fs_round_kernel<<<1, 64, 0, ctx->stream>>>(d_fs, root, run->d_proof + off_roots + 33 * r, last ? nullptr : d_alphas + r);
+        if (last) break;
+        uint32_t *next = nullptr;
+        if (hipMalloc((void **)&next, (cur_len / 2) * 4) != hipSuccess) return bail(smi_fail(ctx, SMI_ERR_OOM, "hipMalloc codeword"));
+        if ((rc = launch_fold(ctx, cur, cur_len, d_alphas + r, offset, omega, next)) != SMI_OK) {
+            hipFree(next);
+            return bail(rc);
+        }
+        cur = next;
+        cur_len /= 2;
+        omega = h_mul(ctx, omega, omega);    // src/fri.rs:146-147
+        offset = h_mul(ctx, offset, offset);
+    }
+    // last codeword in the clear (src/fri.rs:151)
+    emit_codeword_kernel<<<(uint32_t)((cur_len + 255) / 256), 256, 0, ctx->stream>>>(cur, cur_len, run->d_proof + off_last);
+
+    if (do_query) {
+        fs_challenge_kernel<<<1, 64, 0, ctx->stream>>>(d_fs, d_seed_ch);
+        const uint64_t sample_size = R > 1 ? len / 2 : len;  // src/fri.rs:266-270
+        sample_indices_kernel<<<1, 64, 0, ctx->stream>>>(d_seed_ch, sample_size, last_n, (uint32_t)t, d_top, d_reduced);
+        if (R > 1 && t > 0) {
+            for (uint64_t i = 0; i + 1 < R; i++) {
+                layers[i].cw = run->codewords[i];
+                layers[i].cw_next = run->codewords[i + 1];
+                layers[i].nodes = run->trees[i];
+                layers[i].nodes_next = run->trees[i + 1];
+            }
+            if (hipMemcpyAsync(d_layers, layers.data(), sizeof(LayerInfo) * (R - 1), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+                return bail(smi_fail(ctx, SMI_ERR_HIP, "hipMemcpyAsync layers"));
+            query_kernel<<<dim3((uint32_t)t, (uint32_t)(R - 1)), 64, 0, ctx->stream>>>(d_layers, d_top, (uint32_t)t, run->d_proof);
+        }
+    }
+    if (hipGetLastError() != hipSuccess) return bail(smi_fail(ctx, SMI_ERR_HIP, "fri kernel launch"));
+
+    // one synchronising copy-back
+    std::vector<uint8_t> proof(proof_len);
+    if (hipMemcpyAsync(proof.data(), run->d_proof, proof_len, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+        return bail(smi_fail(ctx, SMI_ERR_HIP, "copy proof"));
+    std::vector<uint64_t> alphas(R), top(t + 1);
+    hipMemcpyAsync(alphas.data(), d_alphas, 8 * (R - 1), hipMemcpyDeviceToHost, ctx->stream);
+    if (do_query) hipMemcpyAsync(top.data(), d_top, 8 * t, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return bail(smi_hip_fail(ctx, e, "fri sync"));
+
+    if (roots_host)
+        for (uint64_t r = 0; r < R; r++) memcpy(roots_host + 32 * r, proof.data() + 33 * r + 1, 32);
+    if (alphas_host) memcpy(alphas_host, alphas.data(), 8 * (R - 1));
+    if (last_host) memcpy(last_host, proof.data() + off_last + 9, 8 * last_n);
+    if (last_len) *last_len = last_n;
+    if (top_host && do_query) memcpy(top_host, top.data(), 8 * t);
+    if (proof_host) proof_host->swap(proof);
+    if (run_out) *run_out = run;
+    else smi_fri_run_free(run);
+    return SMI_OK;
+}
+
+// ------------------------------------------------------------------------- C ABI
+int smi_dev_fri_fold(smi_ctx *ctx, const uint32_t *d_in, size_t len, const uint64_t *d_alpha, uint64_t offset,
+                     uint64_t omega, uint32_t *d_out) {
+    if (!ctx || !d_in || !d_alpha || !d_out) return SMI_ERR_BAD_ARG;
+    return launch_fold(ctx, d_in, len, d_alpha, offset, omega, d_out);
+}
+
+int smi_dev_fri_prove(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, size_t len, uint8_t **proof,
+                      size_t *proof_len, uint64_t *top_indices, smi_fri_run **run) {
+    if (!ctx || !cfg || !d_codeword || !proof || !proof_len) return SMI_ERR_BAD_ARG;
+    std::vector<uint8_t> bytes;
+    SMI_TRY(fri_run(ctx, cfg, d_codeword, len, true, run, &bytes, top_indices, nullptr, nullptr, nullptr, nullptr));
+    *proof = (uint8_t *)malloc(bytes.size() ? bytes.size() : 1);
+    if (!*proof) return smi_fail(ctx, SMI_ERR_OOM, "malloc proof");
+    memcpy(*proof, bytes.data(), bytes.size());
+    *proof_len = bytes.size();
+    return SMI_OK;
+}
+
+static int upload_codeword(smi_ctx *ctx, const uint64_t *codeword, size_t len, uint32_t **d_cw) {
+    void *stage;
+    SMI_TRY(ctx_tmp(ctx, 0, len * 8, &stage));
+    if (hipMalloc((void **)d_cw, len * 4 ? len * 4 : 4) != hipSuccess) return smi_fail(ctx, SMI_ERR_OOM, "hipMalloc codeword");
+    HIP_TRY(ctx, hipMemcpyAsync(stage, codeword, len * 8, hipMemcpyHostToDevice, ctx->stream));
+    SMI_TRY(launch_narrow(ctx, (const uint64_t *)stage, *d_cw, len, 0));
+    return check_flag(ctx);
+}
+
+int smi_fri_prove(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint64_t *codeword, size_t len, uint8_t **proof,
+                  size_t *proof_len, uint64_t *top_indices) {
+    if (!ctx || !cfg || !codeword || !proof || !proof_len) return SMI_ERR_BAD_ARG;
+    SMI_TRY(smi_fri_check(ctx, cfg));
+    if (cfg->domain_length != len) return smi_fail(ctx, SMI_ERR_CODEWORD_LEN, "initial codeword length does not match domain length");
+    uint32_t *d_cw = nullptr;
+    int rc = upload_codeword(ctx, codeword, len, &d_cw);
+    if (rc == SMI_OK) rc = smi_dev_fri_prove(ctx, cfg, d_cw, len, proof, proof_len, top_indices, nullptr);
+    hipStreamSynchronize(ctx->stream);
+    hipFree(d_cw);
+    return rc;
+}
+
+int smi_fri_commit(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint64_t *codeword, size_t len, uint8_t *roots,
+                   uint64_t *alphas, uint64_t *last_codeword, size_t *last_len, smi_fri_run **run) {
+    if (!ctx || !cfg || !codeword) return SMI_ERR_BAD_ARG;
+    SMI_TRY(smi_fri_check(ctx, cfg));
+    if (cfg->domain_length != len) return smi_fail(ctx, SMI_ERR_CODEWORD_LEN, "initial codeword length does not match domain length");
+    uint32_t *d_cw = nullptr;
+    int rc = upload_codeword(ctx, codeword, len, &d_cw);
+    smi_fri_run *r = nullptr;
+    if (rc == SMI_OK) rc = fri_run(ctx, cfg, d_cw, len, false, run ? &r : nullptr, nullptr, nullptr, roots, alphas, last_codeword, last_len);
+    hipStreamSynchronize(ctx->stream);
+    if (rc == SMI_OK && run) {
+        r->owns_first = true;  // the run keeps the uploaded codeword
+        *run = r;
+    } else {
+        hipFree(d_cw);
+    }
+    return rc;
+}
+
+int smi_fri_fold(smi_ctx *ctx, const uint64_t *codeword, size_t len, uint64_t alpha, uint64_t offset, uint64_t omega,
+                 uint64_t *out) {
+    if (!ctx || !codeword || !out) return SMI_ERR_BAD_ARG;
+    if (len < 2 || !is_pow2(len)) return smi_fail(ctx, SMI_ERR_BAD_ARG, "fold: codeword length must be a power of two >= 2");
+    void *stage, *d_in, *d_out, *d_alpha;
+    SMI_TRY(ctx_tmp(ctx, 0, len * 8, &stage));
+    SMI_TRY(ctx_tmp(ctx, 1, len * 4, &d_in));
+    SMI_TRY(ctx_tmp(ctx, 2, len * 2 + 8, &d_out));
+    SMI_TRY(ctx_tmp(ctx, 3, 8, &d_alpha));
+    HIP_TRY(ctx, hipMemcpyAsync(stage, codeword, len * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_alpha, &alpha, 8, hipMemcpyHostToDevice, ctx->stream));
+    SMI_TRY(launch_narrow(ctx, (const uint64_t *)stage, (uint32_t *)d_in, len, 0));
+    SMI_TRY(launch_fold(ctx, (const uint32_t *)d_in, len, (const uint64_t *)d_alpha, offset, omega, (uint32_t *)d_out));
+    SMI_TRY(launch_widen(ctx, (const uint32_t *)d_out, (uint64_t *)stage, len / 2));
+    HIP_TRY(ctx, hipMemcpyAsync(out, stage, (len / 2) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    return check_flag(ctx);
+}

@@ -1,0 +1,146 @@
+// hash.hip -- leaf-parallel hash and Merkle tree kernels (gfx950).
+//
+// Replaces Hash::from_field_elements / Hash::combine (reference src/hash.rs:32-46) as they
+// are used per codeword element and per tree node by Fri::commit (src/fri.rs:118-127) and
+// MerkleTree::new (src/merkle.rs:11-38).  One hash per lane, state in VGPRs in the
+// paired-lane layout of hash_core.h.  The tree is kept whole on the device (`nodes` of
+// src/merkle.rs:6, levels back to back) so `open` is a gather and nothing is rebuilt.
+//
+// merkle_sub_kernel: every lane owns 2^K adjacent inputs and builds their K-level subtree
+// on its own (2^K leaf hashes + 2^K - 1 node hashes at full lane occupancy, no cross-lane
+// traffic); child digests wait in an LDS stash laid out [slot][word][thread] (bank =
+// thread, conflict free).  Roofline: integer VALU (~1.6k ops per hash), not HBM.
+#include "hash_core.h"
+#include "internal.h"
+
+#define SMI_HASH_THREADS 256
+
+__device__ __forceinline__ size_t level_offset(size_t n, uint32_t lvl) { return 2 * n - ((2 * n) >> lvl); }
+
+template <bool FROM_ELEMS>
+__global__ __launch_bounds__(SMI_HASH_THREADS) void merkle_sub_kernel(const uint32_t *__restrict__ elems, uint4 *nodes,
+                                                                        size_t n, uint32_t lvl_in, size_t count_in,
+                                                                        uint32_t K) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t stash[];  // [1<<K][8][SMI_HASH_THREADS]
+    const uint32_t tid = threadIdx.x;
+    const size_t t = (size_t)blockIdx.x * SMI_HASH_THREADS + tid;
+    const size_t n_threads = count_in >> K;
+    if (t >= n_threads) return;  // no barriers below: lanes are independent
+    const uint32_t per = 1u << K;
+    const size_t first = t << K;
+    uint32_t d[8];
+    for (uint32_t i = 0; i < per; i++) {
+        if (FROM_ELEMS) {
+            hashc::leaf_hash(elems[first + i], d);
+            uint4 *dst = nodes + 2 * (first + i);
+            dst[0] = make_uint4(d[0], d[1], d[2], d[3]);
+            dst[1] = make_uint4(d[4], d[5], d[6], d[7]);
+        } else {
+            const uint4 *src = nodes + 2 * (level_offset(n, lvl_in) + first + i);
+            const uint4 a = src[0], b = src[1];
+            d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+        }
+#pragma unroll
+        for (int w = 0; w < 8; w++) stash[(i * 8 + w) * SMI_HASH_THREADS + tid] = d[w];
+    }
+    for (uint32_t j = 1; j <= K; j++) {
+        const uint32_t cnt = per >> j;
+        uint4 *dst = nodes + 2 * (level_offset(n, lvl_in + j) + (t << (K - j)));
+        for (uint32_t q = 0; q < cnt; q++) {
+            uint32_t l[8], r[8];
+#pragma unroll
+            for (int w = 0; w < 8; w++) {
+                l[w] = stash[((2 * q) * 8 + w) * SMI_HASH_THREADS + tid];
+                r[w] = stash[((2 * q + 1) * 8 + w) * SMI_HASH_THREADS + tid];
+            }
+            hashc::node_hash(l, r, d);
+            dst[2 * q] = make_uint4(d[0], d[1], d[2], d[3]);
+            dst[2 * q + 1] = make_uint4(d[4], d[5], d[6], d[7]);
+#pragma unroll
+            for (int w = 0; w < 8; w++) stash[(q * 8 + w) * SMI_HASH_THREADS + tid] = d[w];
+        }
+    }
+}
+
+// digests only (Hash::from_field_elements per element)
+__global__ __launch_bounds__(SMI_HASH_THREADS) void leaf_hash_kernel(const uint32_t *__restrict__ elems, uint4 *out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * SMI_HASH_THREADS + threadIdx.x;
+    if (i >= n) return;
+    uint32_t d[8];
+    hashc::leaf_hash(elems[i], d);
+    out[2 * i] = make_uint4(d[0], d[1], d[2], d[3]);
+    out[2 * i + 1] = make_uint4(d[4], d[5], d[6], d[7]);
+}
+
+// out[i] = combine(in[2i], in[2i+1])
+__global__ __launch_bounds__(SMI_HASH_THREADS) void combine_kernel(const uint4 *__restrict__ in, uint4 *out, size_t n_pairs) {
+    const size_t i = (size_t)blockIdx.x * SMI_HASH_THREADS + threadIdx.x;
+    if (i >= n_pairs) return;
+    const uint4 a = in[4 * i], b = in[4 * i + 1], c = in[4 * i + 2], e = in[4 * i + 3];
+    const uint32_t l[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}, r[8] = {c.x, c.y, c.z, c.w, e.x, e.y, e.z, e.w};
+    uint32_t d[8];
+    hashc::node_hash(l, r, d);
+    out[2 * i] = make_uint4(d[0], d[1], d[2], d[3]);
+    out[2 * i + 1] = make_uint4(d[4], d[5], d[6], d[7]);
+}
+
+// Hash::from_bytes of one message, single lane (src/hash.rs:7-30)
+__global__ void hash_bytes_kernel(const uint8_t *msg, size_t len, uint32_t *out) {
+    if (threadIdx.x || blockIdx.x) return;
+    uint32_t d[8];
+    hashc::hash_bytes(msg, len, d);
+    for (int i = 0; i < 8; i++) out[i] = d[i];
+}
+
+// ------------------------------------------------------------------------- launches
+static inline uint32_t blocks_for(size_t threads) { return (uint32_t)((threads + SMI_HASH_THREADS - 1) / SMI_HASH_THREADS); }
+
+int launch_leaf_hash(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_digests) {
+    if (!n) return SMI_OK;
+    leaf_hash_kernel<<<blocks_for(n), SMI_HASH_THREADS, 0, ctx->stream>>>(d_elems, (uint4 *)d_digests, n);
+    HIP_TRY(ctx, hipGetLastError());
+    return SMI_OK;
+}
+int launch_combine(smi_ctx *ctx, const uint8_t *d_in, size_t n_pairs, uint8_t *d_out) {
+    if (!n_pairs) return SMI_OK;
+    combine_kernel<<<blocks_for(n_pairs), SMI_HASH_THREADS, 0, ctx->stream>>>((const uint4 *)d_in, (uint4 *)d_out, n_pairs);
+    HIP_TRY(ctx, hipGetLastError());
+    return SMI_OK;
+}
+int launch_hash_bytes(smi_ctx *ctx, const uint8_t *d_msg, size_t len, uint32_t *d_out) {
+    hash_bytes_kernel<<<1, 64, 0, ctx->stream>>>(d_msg, len, d_out);
+    HIP_TRY(ctx, hipGetLastError());
+    return SMI_OK;
+}
+
+static uint32_t log2_floor(size_t n) {
+    uint32_t l = 0;
+    while ((n >> l) > 1) l++;
+    return l;
+}
+
+// Builds levels (lvl_from, log2 n] of the tree in d_nodes; if d_elems != nullptr level 0 is
+// hashed from the codeword first (fused with the bottom levels).  n must be a power of two.
+int launch_merkle(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_nodes) {
+    const uint32_t depth = log2_floor(n);
+    uint4 *nodes = (uint4 *)d_nodes;
+    uint32_t lvl = 0;
+    size_t count = n;
+    bool from_elems = d_elems != nullptr;
+    const uint32_t KMAX = 2;
+    if (from_elems && depth == 0) return launch_leaf_hash(ctx, d_elems, 1, d_nodes);
+    while (lvl < depth || from_elems) {
+        uint32_t K = depth - lvl < KMAX ? depth - lvl : KMAX;
+        const size_t threads = count >> K;
+        const size_t lds = (size_t)(8u << K) * SMI_HASH_THREADS * sizeof(uint32_t);
+        if (from_elems)
+            merkle_sub_kernel<true><<<blocks_for(threads), SMI_HASH_THREADS, lds, ctx->stream>>>(d_elems, nodes, n, 0, count, K);
+        else
+            merkle_sub_kernel<false><<<blocks_for(threads), SMI_HASH_THREADS, lds, ctx->stream>>>(nullptr, nodes, n, lvl, count, K);
+        HIP_TRY(ctx, hipGetLastError());
+        from_elems = false;
+        lvl += K;
+        count >>= K;
+    }
+    return SMI_OK;
+}

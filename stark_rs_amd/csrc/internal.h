@@ -1,0 +1,73 @@
+// internal.h -- context and helpers shared by the translation units of libstarkmi.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/stark_mi.h"
+#include "tables.h"
+
+struct ScaleEntry {
+    uint32_t c, q, L;
+    uint32_t *lo, *hi;
+};
+
+struct smi_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    FieldSetup fs;
+    uint32_t *d_tab[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};  // [dir][tw10, lo, hi]
+    std::vector<ScaleEntry> scale_cache;
+    uint32_t *scratch = nullptr;   // NTT inter-pass buffer
+    size_t scratch_elems = 0;
+    void *tmp[4] = {nullptr, nullptr, nullptr, nullptr};  // staging buffers of the host-buffer entry points
+    size_t tmp_bytes[4] = {0, 0, 0, 0};
+    int *d_flag = nullptr;         // non-canonical input flag
+    std::string err;
+};
+
+struct smi_tree {
+    smi_ctx *ctx;
+    uint8_t *d_nodes;   // (2n-1) x 32 bytes, level 0 first
+    size_t n;
+    bool owns;
+};
+
+int smi_hip_fail(smi_ctx *ctx, hipError_t e, const char *what);
+#define HIP_TRY(ctx, call)                                             \
+    do {                                                               \
+        hipError_t e__ = (call);                                       \
+        if (e__ != hipSuccess) return smi_hip_fail((ctx), e__, #call); \
+    } while (0)
+#define SMI_TRY(call)            \
+    do {                         \
+        int rc__ = (call);       \
+        if (rc__ != SMI_OK) return rc__; \
+    } while (0)
+
+int smi_fail(smi_ctx *ctx, int code, const char *msg);
+
+// grows (never shrinks) a context-owned staging buffer
+int ctx_tmp(smi_ctx *ctx, int slot, size_t bytes, void **out);
+int ctx_scratch(smi_ctx *ctx, size_t elems, uint32_t **out);
+NttTables ctx_tables(const smi_ctx *ctx, int inverse);
+// device tables of c * q^i, i < 2^L (cached per (c,q,L))
+int ctx_scale_tables(smi_ctx *ctx, uint32_t c_plain, uint32_t q_plain, uint32_t L, ScaleTables *out);
+
+// field helpers on the host (plain form)
+inline uint32_t h_mul(const smi_ctx *c, uint32_t a, uint32_t b) { return host_mulmod(a, b, c->fs.F.p); }
+inline uint32_t h_pow(const smi_ctx *c, uint32_t a, uint64_t e) { return host_powmod(a, e, c->fs.F.p); }
+inline uint32_t h_inv(const smi_ctx *c, uint32_t a) { return host_powmod(a, c->fs.F.p - 2, c->fs.F.p); }
+inline uint32_t h_root(const smi_ctx *c, uint32_t log_n) {  // primitive 2^log_n-th root (forward)
+    return host_powmod(c->fs.wmax[0], 1ull << (c->fs.K - log_n), c->fs.F.p);
+}
+
+// launches (defined in the .hip files)
+int launch_geom_table(smi_ctx *ctx, const GeomSpec &s, uint32_t *d_out);
+int launch_narrow(smi_ctx *ctx, const uint64_t *d_in, uint32_t *d_out, size_t n, int reduce);
+int launch_widen(smi_ctx *ctx, const uint32_t *d_in, uint64_t *d_out, size_t n);
+int dev_ntt(smi_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint32_t log_n, size_t n_in, uint32_t batch,
+            size_t in_stride, size_t out_stride, int inverse, uint64_t offset, uint64_t post_scale);
+int check_flag(smi_ctx *ctx);  // syncs; SMI_ERR_NON_CANONICAL if a narrow kernel saw a value >= p

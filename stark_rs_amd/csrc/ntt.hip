@@ -1,0 +1,151 @@
+// ntt.hip -- gfx950 NTT kernels and their host driver.
+//
+// Replaces Polynomial::interpolate_domain (reference src/univariate/interpolate.rs:6-44),
+// Polynomial::eval_domain (src/univariate/eval.rs:16-21) and Polynomial::scale
+// (src/univariate/mod.rs:99-113) on geometric domains.  Kernel structure, tiling and the
+// roofline that bounds it are described in ntt_core.h and DESIGN.md.
+#include "internal.h"
+#include "ntt_driver.h"
+
+// ------------------------------------------------------------------------- kernels
+template <int LOGR, bool LAST>
+__global__ __launch_bounds__(SMI_NTT_THREADS) void ntt_pass_kernel(const PassArgs a) {
+    typedef NttPass<LOGR, LAST> NP;
+    __shared__ uint32_t tile[NP::R * NP::WP];
+    __shared__ uint32_t tw[NP::R];
+    const uint32_t tid = threadIdx.x, batch = blockIdx.y;
+    const typename NP::TileId t = NP::tile_id(a, blockIdx.x);
+    NP::load_tw(a, tw, tid);
+    NP::load(a, t, batch, tile, tid);
+    __syncthreads();
+    NP::template step_i<0>(a, tile, tw, tid);
+    __syncthreads();
+    NP::template step_i<1>(a, tile, tw, tid);
+    __syncthreads();
+    if (NP::St::n == 3) {
+        NP::template step_i<2>(a, tile, tw, tid);
+        __syncthreads();
+    }
+    NP::store(a, t, batch, tile, tid);
+}
+
+__global__ __launch_bounds__(SMI_NTT_THREADS) void ntt_small_kernel(const SmallArgs a) {
+    __shared__ uint32_t buf[SMI_TILE];
+    const uint32_t tid = threadIdx.x, batch = blockIdx.x;
+    NttSmall::load(a, batch, buf, tid);
+    __syncthreads();
+    for (uint32_t s = 0; s < a.L; s++) {
+        NttSmall::stage(a, s, buf, tid);
+        __syncthreads();
+    }
+    NttSmall::store(a, batch, buf, tid);
+}
+
+__global__ void geom_table_kernel(uint32_t *out, GeomSpec s, Fp F) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < s.count) out[i] = geom_entry(s.c_m, s.q_m, i, s.stride, F);
+}
+
+// u64 (reference wire width, src/stream.rs:45) <-> u32 device residues
+__global__ void narrow_kernel(const uint64_t *in, uint32_t *out, size_t n, uint32_t p, int reduce, int *flag) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    int bad = 0;
+    for (; i < n; i += step) {
+        const uint64_t v = in[i];
+        if (v >= p) bad = 1;
+        out[i] = (uint32_t)(v % p);
+    }
+    if (bad && !reduce) *flag = 1;
+}
+__global__ void widen_kernel(const uint32_t *in, uint64_t *out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += step) out[i] = in[i];
+}
+
+// ------------------------------------------------------------------------- launches
+static uint32_t grid_for(size_t n, uint32_t block) {
+    size_t g = (n + block - 1) / block;
+    return (uint32_t)(g > 2048 ? 2048 : (g ? g : 1));
+}
+
+int launch_geom_table(smi_ctx *ctx, const GeomSpec &s, uint32_t *d_out) {
+    geom_table_kernel<<<(s.count + 255) / 256, 256, 0, ctx->stream>>>(d_out, s, ctx->fs.F);
+    HIP_TRY(ctx, hipGetLastError());
+    return SMI_OK;
+}
+int launch_narrow(smi_ctx *ctx, const uint64_t *d_in, uint32_t *d_out, size_t n, int reduce) {
+    if (!n) return SMI_OK;
+    narrow_kernel<<<grid_for(n, 256), 256, 0, ctx->stream>>>(d_in, d_out, n, ctx->fs.F.p, reduce, ctx->d_flag);
+    HIP_TRY(ctx, hipGetLastError());
+    return SMI_OK;
+}
+int launch_widen(smi_ctx *ctx, const uint32_t *d_in, uint64_t *d_out, size_t n) {
+    if (!n) return SMI_OK;
+    widen_kernel<<<grid_for(n, 256), 256, 0, ctx->stream>>>(d_in, d_out, n);
+    HIP_TRY(ctx, hipGetLastError());
+    return SMI_OK;
+}
+
+namespace {
+struct HipLauncher {
+    smi_ctx *ctx;
+    hipError_t err = hipSuccess;
+    void small(const SmallArgs &a, uint32_t batch) {
+        ntt_small_kernel<<<batch, SMI_NTT_THREADS, 0, ctx->stream>>>(a);
+        note();
+    }
+    void pass(int logr, bool last, const PassArgs &a, uint32_t batch) {
+        const dim3 grid(a.n_tiles, batch);
+#define CASE(LR)                                                                                  \
+    case LR:                                                                                      \
+        if (last) ntt_pass_kernel<LR, true><<<grid, SMI_NTT_THREADS, 0, ctx->stream>>>(a);        \
+        else ntt_pass_kernel<LR, false><<<grid, SMI_NTT_THREADS, 0, ctx->stream>>>(a);            \
+        break;
+        switch (logr) { CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) }
+#undef CASE
+        note();
+    }
+    void note() {
+        hipError_t e = hipGetLastError();
+        if (err == hipSuccess) err = e;
+    }
+};
+}  // namespace
+
+int dev_ntt(smi_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint32_t log_n, size_t n_in, uint32_t batch,
+            size_t in_stride, size_t out_stride, int inverse, uint64_t offset, uint64_t post_scale) {
+    const uint32_t p = ctx->fs.F.p;
+    if (log_n > ctx->fs.K)
+        return smi_fail(ctx, p == 998244353u ? SMI_ERR_ROOT_TOO_LARGE : SMI_ERR_UNSUPPORTED_PRIME,
+                        "transform size exceeds the two-adicity of the modulus");
+    const uint64_t n = 1ull << log_n;
+    if (!batch) return SMI_OK;
+    if (n_in > n || (inverse && n_in != n)) return smi_fail(ctx, SMI_ERR_BAD_ARG, "n_in out of range");
+    if (offset >= p || post_scale >= p) return smi_fail(ctx, SMI_ERR_NON_CANONICAL, "offset/post_scale must be < p");
+    if (offset == 0) return smi_fail(ctx, SMI_ERR_NO_INVERSE, "offset must be invertible");
+    if (batch > 65535) return smi_fail(ctx, SMI_ERR_BAD_ARG, "batch too large");
+    // d_in == d_out is always safe: every pass (and the small kernel) has read all of its
+    // input into LDS / the scratch buffer before anything is written to d_out.
+
+    NttRequest rq;
+    memset(&rq, 0, sizeof rq);
+    rq.in = d_in; rq.out = d_out; rq.L = log_n; rq.n_in = (uint32_t)n_in; rq.batch = batch;
+    rq.in_stride = in_stride; rq.out_stride = out_stride; rq.F = ctx->fs.F;
+    rq.T = ctx_tables(ctx, inverse);
+    if (!inverse) {
+        rq.pre_scale = offset != 1;
+        if (rq.pre_scale) SMI_TRY(ctx_scale_tables(ctx, 1, (uint32_t)offset, log_n, &rq.S));
+    } else {
+        rq.post_scale = true;  // n^-1 * (post_scale/offset)^j
+        const uint32_t ninv = h_inv(ctx, (uint32_t)(n % p));
+        const uint32_t q = h_mul(ctx, (uint32_t)post_scale, h_inv(ctx, (uint32_t)offset));
+        SMI_TRY(ctx_scale_tables(ctx, ninv, q, log_n, &rq.S));
+    }
+    if (log_n > SMI_TILE_LOG) SMI_TRY(ctx_scratch(ctx, (size_t)batch << log_n, &rq.scratch));
+    HipLauncher ln{ctx};
+    ntt_run(ln, rq);
+    if (ln.err != hipSuccess) return smi_hip_fail(ctx, ln.err, "ntt kernel launch");
+    return SMI_OK;
+}

@@ -1,0 +1,56 @@
+// ntt_driver.h -- sequences the passes of one batched transform.  Templated on a
+// Launcher so that the HIP path (ntt.hip) and the CPU emulator of the non-GPU tests
+// (emu.cpp) share every decision about digits, strides, flags and scratch use.
+#pragma once
+#include "ntt_host.h"
+
+struct NttRequest {
+    const uint32_t *in;
+    uint32_t *out;
+    uint32_t *scratch;   // batch * 2^L elements, used when L > SMI_TILE_LOG
+    uint32_t L;
+    uint32_t n_in;       // <= 2^L; inputs beyond it read as zero
+    uint32_t batch;
+    uint64_t in_stride, out_stride;
+    Fp F;
+    NttTables T;         // direction already chosen
+    ScaleTables S;
+    bool pre_scale;      // multiply input i by S(i)   (coset shift of a forward transform)
+    bool post_scale;     // multiply output k by S(k)  (n^-1 * offset^-k of an inverse transform)
+};
+
+// Launcher concept:
+//   void small(const SmallArgs&, uint32_t batch);
+//   void pass(int logr, bool last, const PassArgs&, uint32_t batch);
+template <class Launcher> inline void ntt_run(Launcher &ln, const NttRequest &rq) {
+    const NttPlan pl = ntt_make_plan(rq.L);
+    if (pl.np == 0) {
+        SmallArgs a;
+        a.in = rq.in; a.out = rq.out; a.in_stride = rq.in_stride; a.out_stride = rq.out_stride;
+        a.F = rq.F; a.T = rq.T; a.S = rq.S; a.L = rq.L; a.n_in = rq.n_in;
+        a.flags = (rq.pre_scale ? NTT_PRE_SCALE : 0) | (rq.post_scale ? NTT_POST_SCALE : 0);
+        ln.small(a, rq.batch);
+        return;
+    }
+    const uint64_t n = 1ull << rq.L;
+    uint32_t consumed = 0;
+    for (int p = 0; p < pl.np; p++) {
+        const bool first = p == 0, last = p == pl.np - 1;
+        PassArgs a;
+        memset(&a, 0, sizeof a);
+        a.in = first ? rq.in : rq.scratch;
+        a.in_stride = first ? rq.in_stride : n;
+        a.out = last ? rq.out : rq.scratch;
+        a.out_stride = last ? rq.out_stride : n;
+        a.F = rq.F; a.T = rq.T; a.S = rq.S;
+        a.L = rq.L; a.Sp = consumed; a.n_in = rq.n_in;
+        a.flags = (first ? NTT_FIRST : 0) | (first && rq.pre_scale ? NTT_PRE_SCALE : 0) |
+                  (last && rq.post_scale ? NTT_POST_SCALE : 0);
+        a.d0_log = (uint32_t)pl.logr[0];
+        a.n_mid = (uint32_t)(pl.np - 2);
+        for (int d = 0; d < pl.np - 2; d++) a.mid_log[d] = (uint32_t)pl.logr[1 + d];
+        a.n_tiles = (uint32_t)(n >> SMI_TILE_LOG);
+        ln.pass(pl.logr[p], last, a, rq.batch);
+        consumed += (uint32_t)pl.logr[p];
+    }
+}

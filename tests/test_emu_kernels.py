@@ -1,0 +1,85 @@
+"""CPU: runs the NTT / hash kernels' per-thread phase functions (csrc/ntt_core.h,
+csrc/hash_core.h -- the same code the HIP kernels execute) one "thread" at a time through
+the emulator library and checks them against the oracle.  This is how index / twiddle /
+planning logic is validated in the GPU-less build container; the emulator is test
+infrastructure and is never loaded by the product."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+P, G = 998244353, 3
+P2, G2 = 2013265921, 31
+u32p = C.POINTER(C.c_uint32)
+
+
+@pytest.fixture(scope="module")
+def emu():
+    import stark_rs_amd as s
+    s.build()
+    path = os.path.join(os.path.dirname(s.__file__), "build", "libstarkmi_emu.so")
+    L = C.CDLL(path)
+    L.emu_ntt.argtypes = [C.c_uint64, C.c_uint64, u32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64,
+                          C.c_int, C.c_uint64, C.c_uint64]
+    return L
+
+
+def _ntt(emu, p, g, x, L, n_in, inverse, offset, post=1, batch=1, in_stride=None):
+    x = np.ascontiguousarray(x, dtype=np.uint32)
+    out = np.zeros(batch << L, dtype=np.uint32)
+    rc = emu.emu_ntt(p, g, x.ctypes.data_as(u32p), out.ctypes.data_as(u32p), L, n_in, batch,
+                     (len(x) // batch) if in_stride is None else in_stride, 1 << L, inverse, offset, post)
+    assert rc == 0
+    return out.astype(np.uint64)
+
+
+@pytest.mark.parametrize("p,g", [(P, G), (P2, G2)])
+@pytest.mark.parametrize("L", [0, 1, 4, 9, 12, 13, 14, 15, 16, 17, 18, 19, 20])
+def test_emulated_ntt_every_plan(emu, oracle, p, g, L):
+    o = oracle
+    n = 1 << L
+    w = o.ff_prim_nth_root_g(n, p, g)
+    vals = o.splitmix64(L, n) % np.uint64(p)
+    assert np.array_equal(_ntt(emu, p, g, vals, L, n, 1, 3), o.fast_intt(vals, w, 3, p))
+    nin = max(1, n // 8)
+    assert np.array_equal(_ntt(emu, p, g, vals[:nin], L, nin, 0, 3), o.fast_coset_ntt(vals[:nin], n, w, 3, p))
+
+
+def test_emulated_ntt_three_pass_and_batch(emu, oracle):
+    o = oracle
+    L = 21
+    n = 1 << L
+    w = o.ff_prim_nth_root(n)
+    vals = o.splitmix64(5, n) % np.uint64(P)
+    assert np.array_equal(_ntt(emu, P, G, vals, L, n, 0, 1), o.fast_coset_ntt(vals, n, w, 1))
+    # batch of 3 columns of 2^14, fused post-scale (the LDE's coset shift)
+    L = 14
+    n = 1 << L
+    w = o.ff_prim_nth_root(n)
+    cols = o.splitmix64(6, 3 * n) % np.uint64(P)
+    got = _ntt(emu, P, G, cols, L, n, 1, 1, post=3, batch=3).reshape(3, n)
+    for c in range(3):
+        coeffs = o.fast_intt(cols[c * n:(c + 1) * n], w, 1)
+        assert np.array_equal(got[c], np.array(o.poly_scale(coeffs, 3), dtype=np.uint64))
+
+
+def test_emulated_hash_core(emu, oracle):
+    o = oracle
+    rng = np.random.default_rng(1)
+    v = np.concatenate([np.array([0, 1, 5, P - 1, 0xFFFFFFFF, 255, 256], dtype=np.uint32),
+                        rng.integers(0, 2 ** 32, 500, dtype=np.uint32)])
+    out = np.zeros((len(v), 32), dtype=np.uint8)
+    emu.emu_leaf_hash(v.ctypes.data_as(C.c_void_p), C.c_size_t(len(v)), out.ctypes.data_as(C.c_void_p))
+    for i in range(len(v)):
+        assert bytes(out[i]) == o.hash_from_field_elements([int(v[i])])
+    pairs = rng.integers(0, 256, (200, 64), dtype=np.uint8)
+    out = np.zeros((200, 32), dtype=np.uint8)
+    emu.emu_node_hash(pairs.ctypes.data_as(C.c_void_p), C.c_size_t(200), out.ctypes.data_as(C.c_void_p))
+    for i in range(200):
+        assert bytes(out[i]) == o.hash_combine(bytes(pairs[i, :32]), bytes(pairs[i, 32:]))
+    for n in list(range(0, 70)) + [100, 255, 256, 1000]:
+        m = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        ob = (C.c_uint8 * 32)()
+        emu.emu_hash_bytes(m, C.c_size_t(n), ob)
+        assert bytes(ob) == o.hash_from_bytes(m)

@@ -1,0 +1,264 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, bit-exact.
+Run on the GPU box with `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+P, G = 998244353, 3
+P2, G2 = 2013265921, 31
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import stark_rs_amd as s
+    e = s.Engine(P, G, 0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def eng2():
+    import stark_rs_amd as s
+    e = s.Engine(P2, G2, 0)
+    yield e
+    e.close()
+
+
+def _vals(o, seed, n, p=P):
+    return o.splitmix64(seed, n) % np.uint64(p)
+
+
+def test_scalars(eng, oracle):
+    o = oracle
+    for lg in (1, 3, 10, 20, 23):
+        assert eng.prim_nth_root(1 << lg) == o.ff_prim_nth_root(1 << lg)
+    assert eng.inv(123) == o.ff_inv(123) and eng.exp(3, 100) == o.ff_exp(3, 100)
+    import stark_rs_amd as s
+    with pytest.raises(s.StarkMiError, match="n must be a power of two"):
+        eng.prim_nth_root(6)
+    with pytest.raises(s.StarkMiError, match="n > 2\\^23 not supported"):
+        eng.prim_nth_root(1 << 24)
+    with pytest.raises(s.StarkMiError, match="no inverse"):
+        eng.inv(0)
+
+
+@pytest.mark.parametrize("logn", [0, 1, 2, 3, 5, 8])
+@pytest.mark.parametrize("offset", [1, 3])
+def test_intt_equals_lagrange_oracle(eng, oracle, logn, offset):
+    """Polynomial::interpolate_domain, op-for-op oracle (O(n^3)), n <= 256."""
+    o = oracle
+    n = 1 << logn
+    w = o.ff_prim_nth_root(n)
+    vals = _vals(o, 40 + logn, n)
+    dom = [o.ff_mul(offset, o.ff_exp(w, k)) for k in range(n)]
+    ref = o.poly_interpolate_domain(dom, vals)
+    got = eng.intt(vals, offset)
+    assert o.poly_eq(got, ref)
+    assert list(got) == list(ref)
+
+
+@pytest.mark.parametrize("logd,logN,offset", [(0, 3, 1), (3, 6, 3), (6, 9, 1), (4, 10, 3), (8, 11, 3)])
+def test_coset_ntt_equals_eval_domain_oracle(eng, oracle, logd, logN, offset):
+    """Polynomial::eval_domain, op-for-op oracle (O(N d))."""
+    o = oracle
+    d, N = 1 << logd, 1 << logN
+    W = o.ff_prim_nth_root(N)
+    coeffs = _vals(o, 7 + logd, d)
+    dom = [o.ff_mul(offset, o.ff_exp(W, k)) for k in range(N)]
+    ref = o.poly_eval_domain(coeffs, dom)
+    assert list(eng.coset_ntt(coeffs, logN, offset)) == list(ref)
+
+
+@pytest.mark.parametrize("logn", [10, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23])
+def test_ntt_all_plans_vs_fast_oracle(eng, oracle, logn):
+    """Every pass plan (small kernel, 2-pass, 3-pass) against the oracle's radix-2 restatement
+    (itself proven equal to the O(n^3) path in tests/test_oracle_fast.py)."""
+    o = oracle
+    n = 1 << logn
+    w = o.ff_prim_nth_root(n)
+    vals = _vals(o, logn, n)
+    assert np.array_equal(eng.intt(vals, 3), o.fast_intt(vals, w, 3))
+    nin = n // 8
+    assert np.array_equal(eng.coset_ntt(vals[:nin], logn, 3), o.fast_coset_ntt(vals[:nin], n, w, 3))
+    assert np.array_equal(eng.coset_ntt(vals, logn, 1), o.fast_coset_ntt(vals, n, w, 1))
+
+
+def test_ntt_cfg2_2p20_roundtrip_and_sampled_oracle(eng, oracle):
+    """BASELINE configs[1]: 2^20-point forward+inverse.  Full-size checks: round trip, and the
+    op-for-op oracle's Polynomial::eval at sampled domain points."""
+    o = oracle
+    n = 1 << 20
+    w = o.ff_prim_nth_root(n)
+    assert w == 565042129
+    vals = _vals(o, 2, n)
+    coeffs = eng.intt(vals, 1)
+    back = eng.coset_ntt(coeffs, 20, 1)
+    assert np.array_equal(back, vals)
+    for k in (0, 1, 12345, n // 2, n - 1):
+        assert o.poly_eval(coeffs, o.ff_exp(w, k)) == int(vals[k])
+
+
+def test_second_prime_sizes_above_2p23(eng2, oracle):
+    o = oracle
+    for logn in (16, 24, 25):
+        n = 1 << logn
+        w = o.ff_prim_nth_root_g(n, P2, G2)
+        vals = _vals(o, logn, n, P2)
+        assert np.array_equal(eng2.intt(vals, 31), o.fast_intt(vals, w, 31, P2))
+        assert np.array_equal(eng2.coset_ntt(vals[: n // 8], logn, 31), o.fast_coset_ntt(vals[: n // 8], n, w, 31, P2))
+
+
+def test_poly_scale(eng, oracle):
+    o = oracle
+    assert list(eng.poly_scale([1, 2, 3], 2)) == [1, 4, 12]          # mod.rs:439-456
+    c = _vals(o, 3, 1000)
+    assert list(eng.poly_scale(c, 12345)) == o.poly_scale(c, 12345)
+
+
+def test_lde_cfg3_small(eng, oracle):
+    """4 columns, blowup 8: interpolate on the subgroup, evaluate on the coset g*<W>."""
+    o = oracle
+    logn, lb = 12, 3
+    n, N = 1 << logn, 1 << (logn + lb)
+    w, W = o.ff_prim_nth_root(n), o.ff_prim_nth_root(N)
+    cols = np.stack([_vals(o, 0x5354524B00 + c, n) for c in range(4)])
+    out = eng.lde(cols, lb, 1, 3)
+    for c in range(4):
+        coeffs = o.fast_intt(cols[c], w, 1)
+        assert np.array_equal(out[c], o.fast_coset_ntt(coeffs, N, W, 3))
+
+
+def test_non_canonical_input_rejected(eng):
+    import stark_rs_amd as s
+    v = np.array([1, 2, P, 4], dtype=np.uint64)
+    with pytest.raises(s.StarkMiError, match="canonical"):
+        eng.intt(v, 1)
+
+
+# ------------------------------------------------------------------ hash / merkle
+def test_leaf_hashes(eng, oracle):
+    o = oracle
+    v = np.concatenate([np.array([0, 1, 5, P - 1, 255, 256, 65535, 65536], dtype=np.uint64), _vals(o, 5, 3000)])
+    got = eng.hash_leaves(v)
+    want = o.leaf_hashes(v)
+    assert np.array_equal(got, want)
+    assert bytes(got[2]).hex() == "b41399e39a0d1249b4f0318e5e6416ccaa2dffb01519bf1296173be9c10b5f06"
+
+
+def test_combine_and_bytes(eng, oracle):
+    o = oracle
+    rng = np.random.default_rng(3)
+    pairs = rng.integers(0, 256, (300, 64), dtype=np.uint8)
+    got = eng.hash_combine_pairs(pairs)
+    for i in range(300):
+        assert bytes(got[i]) == o.hash_combine(bytes(pairs[i, :32]), bytes(pairs[i, 32:]))
+    for n in (0, 1, 5, 8, 31, 32, 33, 64, 65, 100, 1000):
+        m = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert eng.hash_bytes(m) == o.hash_from_bytes(m)
+    assert eng.hash_bytes(b"hello").hex() == "663afaa74185a1693451aa7fd22ac722ff8f89aabc0471f28dc7c2b7354cae8e"
+
+
+@pytest.mark.parametrize("logn", [0, 1, 2, 3, 4, 7, 10, 13, 16])
+def test_merkle_tree_all_levels(eng, oracle, logn):
+    o = oracle
+    n = 1 << logn
+    cw = _vals(o, 77 + logn, n)
+    tree = eng.merkle_from_codeword(cw)
+    nodes = o.merkle_new(o.leaf_hashes(cw))
+    off = 0
+    for lvl in range(logn + 1):
+        cnt = n >> lvl
+        assert np.array_equal(tree.level(lvl), nodes[off:off + cnt]), lvl
+        off += cnt
+    assert tree.root() == bytes(nodes[-1])
+    for i in {0, n - 1, n // 2, (n * 3) // 7}:
+        path = tree.open(i)
+        assert path == o.merkle_open(nodes, n, i)
+        assert o.merkle_verify(bytes(nodes[i]), i, path, tree.root())
+    tree.free()
+
+
+def test_merkle_from_digest_leaves_and_panics(eng, oracle):
+    import stark_rs_amd as s
+    o = oracle
+    leaves = np.stack([np.frombuffer(o.hash_from_bytes(bytes([i])), dtype=np.uint8) for i in range(8)])
+    assert eng.merkle_commit(leaves).hex() == "d86d7c3c1368c029ff23248875ffb2fb673459897e3dcbd67ac0e09ca4cdd738"
+    t = eng.merkle_new(leaves)
+    for i in range(8):                                                  # merkle.rs:113-122
+        assert o.merkle_verify(bytes(leaves[i]), i, t.open(i), t.root())
+    with pytest.raises(s.StarkMiError, match="Index out of bounds"):
+        t.open(8)
+    with pytest.raises(s.StarkMiError, match="Number of leaves must be power of 2"):
+        eng.merkle_new(leaves[:3])
+    with pytest.raises(s.StarkMiError, match="Cannot create tree from empty leaves"):
+        eng.merkle_new(leaves[:0])
+
+
+# ------------------------------------------------------------------ fri
+@pytest.mark.parametrize("logn", [1, 2, 6, 10, 16])
+def test_fold_equals_reference_fold(eng, oracle, logn):
+    o = oracle
+    n = 1 << logn
+    omega = o.ff_prim_nth_root(n)
+    cfg = o.fri_cfg(omega, 3, n, 4, 1)
+    cw = _vals(o, 11, n)
+    for alpha in (0, 1, P - 1, P, 0xFFFFFFFFFFFFFFFF, 0x0123456789ABCDEF):
+        want = o.fri_fold_codeword(cfg, cw, alpha, 3, omega) if logn <= 10 else o.fast_fold(cw, alpha, 3, omega)
+        assert np.array_equal(eng.fri_fold(cw, alpha, 3, omega), want)
+
+
+def _domain(o, omega, offset, n):
+    return [o.ff_mul(offset, o.ff_exp(omega, i)) for i in range(n)]
+
+
+@pytest.mark.parametrize("n,exp,t,offset,coeffs", [
+    (32, 4, 2, 3, [5]),                         # fri.rs:533-563
+    (64, 4, 3, 7, [5, 3]),                      # fri.rs:566-601
+    (128, 4, 4, 13, [1, 3, 2]),                 # fri.rs:604-646
+    (256, 8, 5, 17, [1, 2, 5, 3, 7, 4, 1, 2]),  # fri.rs:649-693
+])
+def test_fri_prove_reference_cases_byte_identical_and_verified(eng, oracle, n, exp, t, offset, coeffs):
+    """The reference's four FRI tests: GPU proof bytes == oracle proof bytes, and the oracle's
+    Fri::verify accepts the GPU proof."""
+    o = oracle
+    omega = o.ff_prim_nth_root(n)
+    codeword = o.poly_eval_domain(coeffs, _domain(o, omega, offset, n))
+    ocfg = o.fri_cfg(omega, offset, n, exp, t)
+    want_proof, want_top = o.fri_prove(ocfg, codeword)
+    cfg = eng.fri_cfg(omega, offset, n, exp, t)
+    proof, top = eng.fri_prove(cfg, codeword)
+    assert top == want_top
+    assert proof == want_proof
+    assert o.fri_verify(ocfg, proof), o.fri_last_reject()
+
+
+def test_fri_commit_trace_and_larger_prove(eng, oracle):
+    o = oracle
+    n, exp, t, offset = 1 << 14, 8, 16, 3
+    omega = o.ff_prim_nth_root(n)
+    coeffs = _vals(o, 99, n // exp)
+    codeword = o.fast_coset_ntt(coeffs, n, omega, offset)
+    ocfg = o.fri_cfg(omega, offset, n, exp, t)
+    cfg = eng.fri_cfg(omega, offset, n, exp, t)
+    roots, alphas, last = eng.fri_commit(cfg, codeword)
+    wroots, walphas, wlast = o.fri_commit_trace(ocfg, codeword)
+    assert np.array_equal(roots, wroots) and alphas == walphas and np.array_equal(last, wlast)
+    proof, top = eng.fri_prove(cfg, codeword)
+    wproof, wtop = o.fri_prove(ocfg, codeword)
+    assert top == wtop and proof == wproof
+    assert o.fri_verify(ocfg, proof), o.fri_last_reject()
+
+
+def test_fri_panics(eng, oracle):
+    import stark_rs_amd as s
+    o = oracle
+    with pytest.raises(s.StarkMiError, match="Domain length must be power of 2"):
+        eng.fri_cfg(3, 3, 48, 4, 2)
+    with pytest.raises(s.StarkMiError, match="Expansion factor must be power of 2"):
+        eng.fri_cfg(3, 3, 64, 6, 2)
+    with pytest.raises(s.StarkMiError, match="Expansion factor must be at least 4"):
+        eng.fri_cfg(3, 3, 64, 2, 2)
+    cfg = eng.fri_cfg(o.ff_prim_nth_root(32), 3, 32, 4, 2)
+    with pytest.raises(s.StarkMiError, match="initial codeword length does not match domain length"):
+        eng.fri_prove(cfg, [5] * 16)
