@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline measurement (contract in the task statement, section 4).
+
+Metric (BASELINE.json): NTT field-elements/s on the 2^22-row trace at blowup 8 (+ prove time).
+Workload at every N: each rank holds its own 4-column x 2^22-row synthetic trace resident in HBM
+(u32 residues of the second prime 2013265921 = 15*2^27+1, because the reference prime
+998244353 has no 2^25 domain -- SURVEY F2/H1).  One step = the batched low-degree extension of
+that trace: 4 inverse NTTs of 2^22 points + 4 coset NTTs of 2^25 points.  Columns are independent
+units, so ranks share no data-path collective (weak scaling); value = NTT points transformed by
+all ranks per second.  Reported beside it in the same JSON line:
+  * roofline    -- the dominant kernel's achieved HBM GB/s from HIP events around every launch
+                   in the timed region (algorithmic bytes: 8 B per point per pass);
+  * cpu_baseline-- the op-for-op CPU oracle of the reference path on a bounded sample (rank 0);
+  * prove_ms    -- end-to-end build-defined prove (LDE + 4 column commits + combine + Fri::prove)
+                   of the same trace, with per-stage HIP-event times;
+  * ntt_2p20    -- BASELINE configs[1]: 2^20-point forward+inverse on the reference prime;
+  * four_step   -- (N > 1) one 2^26-point NTT sharded over the N GPUs with the RCCL all-to-all.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+LOG_ROWS, LOG_BLOWUP, N_COLS, N_TESTS = 22, 3, 4, 32
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def splitmix64(seed, n):
+    with np.errstate(over="ignore"):
+        i = np.arange(1, n + 1, dtype=np.uint64)
+        z = np.uint64(seed) + i * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def cpu_baseline():
+    """The reference's own CPU algorithms (oracle = op-for-op port; Rust toolchain absent) on a
+    bounded sample of the same path: Lagrange interpolate_domain + power-sum eval_domain."""
+    from oracle import oracle as o
+    o.build()
+    p = o.P_REF
+    n, N = 1 << 10, 1 << 13
+    w, W = o.ff_prim_nth_root(n), o.ff_prim_nth_root(N)
+    vals = splitmix64(1, n) % np.uint64(p)
+    dom = [o.ff_exp(w, k) for k in range(n)]
+    dom_big = [o.ff_mul(3, o.ff_exp(W, k)) for k in range(N)]
+    t0 = time.perf_counter()
+    coeffs = o.poly_interpolate_domain(dom, vals)
+    t1 = time.perf_counter()
+    o.poly_eval_domain(coeffs, dom_big)
+    t2 = time.perf_counter()
+    # the fair algorithmic baseline: the oracle's radix-2 restatement, same arithmetic, 1 thread
+    big = splitmix64(2, 1 << 20) % np.uint64(p)
+    w20, w23 = o.ff_prim_nth_root(1 << 20), o.ff_prim_nth_root(1 << 23)
+    t3 = time.perf_counter()
+    c20 = o.fast_intt(big, w20, 1)
+    o.fast_coset_ntt(c20, 1 << 23, w23, 3)
+    t4 = time.perf_counter()
+    return {
+        "value": (n + N) / (t2 - t0), "unit": "field-elements/s", "cores": 1, "kind": "port",
+        "sample": f"oracle interpolate_domain n=2^10 ({t1 - t0:.2f}s) + eval_domain d=2^10,N=2^13 ({t2 - t1:.2f}s), "
+                  "single thread, same u128 %% p arithmetic and O(n^3)/O(N*d) algorithms as the reference",
+        "fast_ntt_value": ((1 << 20) + (1 << 23)) / (t4 - t3),
+        "fast_ntt_sample": f"oracle radix-2 iNTT 2^20 + coset NTT 2^23, 1 thread ({t4 - t3:.2f}s)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-extras", action="store_true", help="skip prove / 2^20 / four-step / cpu legs")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import stark_rs_amd as s
+    from stark_rs_amd.fourstep import FourStepNTT, HipBackend
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+
+    eng = s.Engine(s.P2, s.G2, local_rank)
+    p = s.P2
+    n, N = 1 << LOG_ROWS, 1 << (LOG_ROWS + LOG_BLOWUP)
+
+    # synthetic trace, column c of rank r seeded 0x5354524B00 + 4r + c, resident in HBM
+    host = np.concatenate([(splitmix64(0x5354524B00 + N_COLS * rank + c, n) % np.uint64(p)).astype(np.uint32)
+                           for c in range(N_COLS)])
+    trace = torch.from_numpy(host.view(np.int32)).to(dev)
+    out = torch.empty(N_COLS * N, dtype=torch.int32, device=dev)
+
+    def step():
+        eng.dev_lde(trace.data_ptr(), N_COLS, LOG_ROWS, LOG_BLOWUP, out.data_ptr())
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    eng.profile(True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernels = eng.profile_read()
+    eng.profile(False)
+    if distributed:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    points_per_step = N_COLS * (n + N)                      # transform sizes summed over the batch
+    value = world * points_per_step * args.steps / elapsed
+
+    # roofline of the dominant kernel (largest total time in the timed region)
+    dom_name, dom = max(kernels.items(), key=lambda kv: kv[1]["total_ms"])
+    avg_ms = dom["total_ms"] / dom["launches"]
+    bytes_per_launch = dom["alg_bytes"] / dom["launches"]
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path):
+        try:
+            traffic = json.load(open(pmc_path)).get(dom_name, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    ntt_ms = sum(k["total_ms"] for k in kernels.values()) / args.steps
+    roofline = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "avg_launch_ms": avg_ms, "alg_bytes_per_launch": bytes_per_launch,
+                # whole-LDE view: SURVEY 8(d) (12+4B)*n*4 cols algorithmic bytes over the step's kernel time
+                "step_alg_bytes": (12 + 4 * (1 << LOG_BLOWUP)) * n * N_COLS,
+                "step_achieved": (12 + 4 * (1 << LOG_BLOWUP)) * n * N_COLS / (ntt_ms * 1e-3) / 1e9,
+                "kernels": {k: {"launches": v["launches"], "avg_ms": v["total_ms"] / v["launches"],
+                                "GBps": v["alg_bytes"] / (v["total_ms"] * 1e-3) / 1e9} for k, v in kernels.items()}}
+
+    result = {
+        "metric": "ntt_field_elements_per_sec", "value": value, "unit": "field-elements/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "lde_2^22rows_x4cols_blowup8 (4 iNTT 2^22 + 4 coset NTT 2^25 per GPU per step)",
+                   "prime": p, "points_per_step_per_gpu": points_per_step, "parallelism": f"columns x{world} (no collective)"},
+        "roofline": roofline,
+    }
+
+    if not args.no_extras:
+        # ---- end-to-end prove of the same trace (build-defined composition)
+        try:
+            eng.dev_stark_prove(trace.data_ptr(), N_COLS, LOG_ROWS, LOG_BLOWUP, N_TESTS)   # warm-up (sizes the arena)
+            barrier()
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            res = eng.dev_stark_prove(trace.data_ptr(), N_COLS, LOG_ROWS, LOG_BLOWUP, N_TESTS, timed=True)
+            prove_ms = 1e3 * (time.perf_counter() - tp)
+            if distributed:
+                tt = torch.tensor([prove_ms], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                prove_ms = float(tt.item())
+            result["prove_ms"] = prove_ms
+            result["prove_stage_ms"] = res["stage_ms"]
+            result["prove_proof_bytes"] = len(res["proof"])
+        except Exception as e:  # reported, never hidden
+            result["prove_error"] = str(e)
+
+        # ---- BASELINE configs[1]: 2^20-point forward + inverse on the reference prime
+        if rank == 0:
+            e1 = s.Engine(s.P_REF, s.G_REF, local_rank)
+            x = torch.from_numpy((splitmix64(2, 1 << 20) % np.uint64(s.P_REF)).astype(np.uint32).view(np.int32)).to(dev)
+            y = torch.empty_like(x)
+            for _ in range(5):
+                e1.dev_ntt(x.data_ptr(), y.data_ptr(), 20, inverse=True)
+                e1.dev_ntt(y.data_ptr(), x.data_ptr(), 20)
+            torch.cuda.synchronize()
+            reps = 200
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                e1.dev_ntt(x.data_ptr(), y.data_ptr(), 20, inverse=True)
+                e1.dev_ntt(y.data_ptr(), x.data_ptr(), 20)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            result["ntt_2p20"] = {"field_elements_per_s": 2 * reps * (1 << 20) / dt, "us_per_transform": 1e6 * dt / (2 * reps),
+                                  "prime": s.P_REF}
+            e1.close()
+
+        # ---- BASELINE configs[3]: 2^26-point four-step NTT sharded over the N GPUs
+        if distributed:
+            lr, lc = 13, 13
+            fs = FourStepNTT(HipBackend(eng), lr, lc, p, rank, world)
+            ncl = (1 << lc) // world
+            cols = torch.from_numpy((splitmix64(4 + rank, ncl << lr) % np.uint64(p)).astype(np.uint32).view(np.int32)).to(dev)
+            fs.forward(cols.clone(), offset=1)
+            torch.cuda.synchronize()
+            barrier()
+            reps = 10
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                fs.forward(cols, offset=1)
+            torch.cuda.synchronize()
+            barrier()
+            dt = time.perf_counter() - t1
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            result["four_step_2p26"] = {"field_elements_per_s": reps * (1 << 26) / float(tt.item()),
+                                        "ms_per_transform": 1e3 * float(tt.item()) / reps, "scaling": "strong"}
+
+        if rank == 0 and world == 1:
+            result["cpu_baseline"] = cpu_baseline()
+
+    if rank == 0:
+        print(json.dumps(result))
+    eng.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

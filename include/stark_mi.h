@@ -79,6 +79,17 @@ void smi_ctx_destroy(smi_ctx *ctx);
 /* Use an existing hipStream_t (e.g. torch's current stream) for everything enqueued. */
 int smi_ctx_set_stream(smi_ctx *ctx, void *hip_stream);
 int smi_ctx_sync(smi_ctx *ctx);
+/* Per-kernel timing with HIP events on the context's stream (bench.py's roofline leg):
+ * while enabled, every hot-path kernel launch is bracketed by two events.
+ * smi_ctx_profile_read synchronises, aggregates by kernel name and clears the log. */
+typedef struct {
+    char name[56];
+    uint32_t launches;
+    double total_ms;
+    double alg_bytes;   /* algorithmic bytes summed over the launches (DESIGN.md states the per-unit figures) */
+} smi_kernel_time;
+int smi_ctx_profile(smi_ctx *ctx, int enable);
+int smi_ctx_profile_read(smi_ctx *ctx, smi_kernel_time *out, size_t cap, size_t *n);
 uint64_t smi_ctx_modulus(const smi_ctx *ctx);
 uint32_t smi_ctx_two_adicity(const smi_ctx *ctx);
 
@@ -200,6 +211,25 @@ int smi_dev_fri_fold(smi_ctx *ctx, const uint32_t *d_in, size_t len, const uint6
  * index sampling run in single-lane device kernels. */
 int smi_dev_fri_prove(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, size_t len, uint8_t **proof,
                       size_t *proof_len, uint64_t *top_indices, smi_fri_run **run);
+
+/* out[i] = sum_c (weights[c] mod p) * cols[c*stride + i]; d_weights holds n_cols unreduced u64
+ * challenges on the device (random linear combination of committed columns; build-defined,
+ * the reference has no prover above Fri::prove -- SURVEY F5). */
+int smi_dev_combine_columns(smi_ctx *ctx, const uint32_t *d_cols, uint32_t n_cols, size_t len, size_t stride,
+                            const uint64_t *d_weights, uint32_t *d_out);
+/* Build-defined composition of the reference primitives: column-major device
+ * trace -> LDE (blowup 2^log_blowup on the coset lde_offset*<w_N>) -> one Merkle tree per column
+ * (one element per leaf, src/fri.rs:118-121) -> fresh FiatShamir absorbs the column roots and
+ * draws one weight per column -> Fri::prove (src/fri.rs:250-311, expansion_factor = blowup) on
+ * the weighted sum.  column_roots (host, optional) gets n_cols x 32 bytes; *proof is the
+ * serialized FRI ProofStream (smi_free); stage_ms (optional) gets the HIP-event times of
+ * {lde, column commits, combine, fri} in milliseconds. */
+typedef struct {
+    uint32_t log_n, log_blowup, n_cols, reserved;
+    uint64_t trace_offset, lde_offset, num_colinearity_tests;
+} smi_stark_cfg;
+int smi_dev_stark_prove(smi_ctx *ctx, const smi_stark_cfg *cfg, const uint32_t *d_trace_cols, uint8_t *column_roots,
+                        uint8_t **proof, size_t *proof_len, uint64_t *top_indices, double *stage_ms);
 
 /* Four-step NTT building blocks for one transform sharded over G GPUs: one
  * process per GPU; the all-to-all between the two local steps belongs to the caller

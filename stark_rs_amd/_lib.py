@@ -28,6 +28,15 @@ class StarkMiError(RuntimeError):
         self.status = status
 
 
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 56), ("launches", C.c_uint32), ("total_ms", C.c_double), ("alg_bytes", C.c_double)]
+
+
+class StarkCfg(C.Structure):
+    _fields_ = [("log_n", C.c_uint32), ("log_blowup", C.c_uint32), ("n_cols", C.c_uint32), ("reserved", C.c_uint32),
+                ("trace_offset", C.c_uint64), ("lde_offset", C.c_uint64), ("num_colinearity_tests", C.c_uint64)]
+
+
 class FriCfg(C.Structure):
     _fields_ = [("omega", C.c_uint64), ("offset", C.c_uint64), ("domain_length", C.c_uint64),
                 ("expansion_factor", C.c_uint64), ("num_colinearity_tests", C.c_uint64)]
@@ -70,6 +79,8 @@ def lib():
         "smi_ctx_destroy": (None, [vp]),
         "smi_ctx_set_stream": (i32, [vp, vp]),
         "smi_ctx_sync": (i32, [vp]),
+        "smi_ctx_profile": (i32, [vp, i32]),
+        "smi_ctx_profile_read": (i32, [vp, vp, sz, C.POINTER(sz)]),
         "smi_ctx_modulus": (C.c_uint64, [vp]),
         "smi_ctx_two_adicity": (C.c_uint32, [vp]),
         "smi_prim_nth_root": (i32, [vp, C.c_uint64, u64p]),
@@ -111,6 +122,8 @@ def lib():
         "smi_dev_merkle_from_digests": (i32, [vp, sz, vp]),
         "smi_dev_fri_fold": (i32, [vp, vp, sz, vp, C.c_uint64, C.c_uint64, vp]),
         "smi_dev_fri_prove": (i32, [vp, C.POINTER(FriCfg), vp, sz, C.POINTER(vp), C.POINTER(sz), vp, C.POINTER(vp)]),
+        "smi_dev_combine_columns": (i32, [vp, vp, C.c_uint32, sz, sz, vp, vp]),
+        "smi_dev_stark_prove": (i32, [vp, C.POINTER(StarkCfg), vp, vp, C.POINTER(vp), C.POINTER(sz), vp, vp]),
         "smi_dev_fourstep_twiddle_pack": (i32, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                                 i32, C.c_uint64]),
         "smi_dev_transpose": (i32, [vp, vp, vp, sz, sz]),

@@ -100,6 +100,8 @@ void smi_ctx_destroy(smi_ctx *ctx) {
         (void)hipFree(e.hi);
     }
     (void)hipFree(ctx->scratch);
+    (void)hipFree(ctx->arena);
+    for (void *q : ctx->arena_overflow) (void)hipFree(q);
     for (int i = 0; i < 4; i++) (void)hipFree(ctx->tmp[i]);
     (void)hipFree(ctx->d_flag);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -119,6 +121,37 @@ int smi_ctx_sync(smi_ctx *ctx) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return SMI_OK;
 }
+int smi_ctx_profile(smi_ctx *ctx, int enable) {
+    if (!ctx) return SMI_ERR_BAD_ARG;
+    ctx->prof_on = enable != 0;
+    return SMI_OK;
+}
+int smi_ctx_profile_read(smi_ctx *ctx, smi_kernel_time *out, size_t cap, size_t *n) {
+    if (!ctx || !n || (cap && !out)) return SMI_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    size_t cnt = 0;
+    for (ProfRec &r : ctx->prof) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+        size_t k = 0;
+        for (; k < cnt; k++)
+            if (!strncmp(out[k].name, r.name, sizeof out[k].name - 1)) break;
+        if (k == cnt) {
+            if (cnt == cap) continue;
+            memset(&out[k], 0, sizeof out[k]);
+            strncpy(out[k].name, r.name, sizeof out[k].name - 1);
+            cnt++;
+        }
+        out[k].launches++;
+        out[k].total_ms += ms;
+        out[k].alg_bytes += r.bytes;
+    }
+    ctx->prof.clear();
+    *n = cnt;
+    return SMI_OK;
+}
 uint64_t smi_ctx_modulus(const smi_ctx *ctx) { return ctx ? ctx->fs.F.p : 0; }
 uint32_t smi_ctx_two_adicity(const smi_ctx *ctx) { return ctx ? ctx->fs.K : 0; }
 
@@ -134,6 +167,40 @@ int ctx_tmp(smi_ctx *ctx, int slot, size_t bytes, void **out) {
     }
     *out = ctx->tmp[slot];
     return SMI_OK;
+}
+int arena_reset(smi_ctx *ctx) {
+    if (!ctx->arena_overflow.empty() || ctx->arena_want > ctx->arena_size) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (void *q : ctx->arena_overflow) (void)hipFree(q);
+        ctx->arena_overflow.clear();
+        if (ctx->arena_want > ctx->arena_size) {
+            (void)hipFree(ctx->arena);
+            ctx->arena = nullptr;
+            ctx->arena_size = 0;
+            const size_t want = ctx->arena_want + ctx->arena_want / 16 + (1u << 20);
+            if (hipMalloc((void **)&ctx->arena, want) == hipSuccess) ctx->arena_size = want;
+            else (void)hipGetLastError();
+        }
+    }
+    ctx->arena_used = 0;
+    ctx->arena_want = 0;
+    return SMI_OK;
+}
+void *arena_alloc(smi_ctx *ctx, size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    ctx->arena_want += bytes;
+    if (ctx->arena_used + bytes <= ctx->arena_size) {
+        void *q = ctx->arena + ctx->arena_used;
+        ctx->arena_used += bytes;
+        return q;
+    }
+    void *q = nullptr;
+    if (hipMalloc(&q, bytes ? bytes : 256) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    ctx->arena_overflow.push_back(q);
+    return q;
 }
 int ctx_scratch(smi_ctx *ctx, size_t elems, uint32_t **out) {
     if (elems > ctx->scratch_elems) {

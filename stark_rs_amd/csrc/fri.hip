@@ -221,16 +221,34 @@ struct smi_fri_run {
     void *d_misc;                       // fs state, alphas, indices, layer table
     uint8_t *d_proof;
     bool owns_first;                    // codewords[0] allocated by us (vs caller's buffer)
+    bool arena;                         // buffers live in the context arena (not retained past the call)
 };
+static void *run_alloc(smi_fri_run *run, size_t bytes) {
+    if (run->arena) return arena_alloc(run->ctx, bytes);
+    void *q = nullptr;
+    if (hipMalloc(&q, bytes ? bytes : 4) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return q;
+}
 
 void smi_fri_run_free(smi_fri_run *run) {
     if (!run) return;
-    hipStreamSynchronize(run->ctx->stream);
+    if (run->arena) {  // arena memory is recycled by the next arena_reset
+        if (run->owns_first && !run->codewords.empty()) {
+            (void)hipStreamSynchronize(run->ctx->stream);
+            (void)hipFree(run->codewords[0]);
+        }
+        delete run;
+        return;
+    }
+    (void)hipStreamSynchronize(run->ctx->stream);
     for (size_t i = 0; i < run->codewords.size(); i++)
-        if (i > 0 || run->owns_first) hipFree(run->codewords[i]);
-    for (uint8_t *t : run->trees) hipFree(t);
-    hipFree(run->d_misc);
-    hipFree(run->d_proof);
+        if (i > 0 || run->owns_first) (void)hipFree(run->codewords[i]);
+    for (uint8_t *t : run->trees) (void)hipFree(t);
+    (void)hipFree(run->d_misc);
+    (void)hipFree(run->d_proof);
     delete run;
 }
 
@@ -246,6 +264,7 @@ int launch_fold(smi_ctx *ctx, const uint32_t *d_in, size_t len, const uint64_t *
     const uint32_t inv2_m = (uint32_t)(((uint64_t)h_inv(ctx, 2) << 32) % p);
     uint32_t grid = (half + 255) / 256;
     if (grid > 2048) grid = 2048;
+    ProfScope ps(ctx, "fri_fold_kernel", 6.0 * (double)len);  // read L*4, write L/2*4
     fri_fold_kernel<<<grid, 256, 0, ctx->stream>>>(d_in, d_out, half, d_alpha, ctx->fs.F, S, inv2_m);
     HIP_TRY(ctx, hipGetLastError());
     return SMI_OK;
@@ -272,7 +291,7 @@ static MiscLayout misc_layout(uint64_t R, uint64_t t) {
 
 // Fri::commit (+ optionally the query phase of Fri::prove) over a device codeword.
 // With do_query == false only roots/alphas/last codeword are produced.
-static int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, size_t len, bool do_query,
+int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, size_t len, bool do_query, bool reset_arena,
                    smi_fri_run **run_out, std::vector<uint8_t> *proof_host, uint64_t *top_host, uint8_t *roots_host,
                    uint64_t *alphas_host, uint64_t *last_host, size_t *last_len) {
     SMI_TRY(smi_fri_check(ctx, cfg));
@@ -292,6 +311,8 @@ static int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codew
     smi_fri_run *run = new smi_fri_run();
     run->ctx = ctx;
     run->owns_first = false;
+    run->arena = run_out == nullptr;   // nothing outlives the call: use the recycled arena
+    if (run->arena && reset_arena) (void)arena_reset(ctx);
     run->d_misc = nullptr;
     run->d_proof = nullptr;
     int rc = SMI_OK;
@@ -318,8 +339,8 @@ static int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codew
     const size_t proof_len = do_query ? off : off_layers;
 
     const MiscLayout ml = misc_layout(R, t);
-    if (hipMalloc(&run->d_misc, ml.total) != hipSuccess) return bail(smi_fail(ctx, SMI_ERR_OOM, "hipMalloc misc"));
-    if (hipMalloc((void **)&run->d_proof, proof_len) != hipSuccess) return bail(smi_fail(ctx, SMI_ERR_OOM, "hipMalloc proof"));
+    if (!(run->d_misc = run_alloc(run, ml.total))) return bail(smi_fail(ctx, SMI_ERR_OOM, "alloc misc"));
+    if (!(run->d_proof = (uint8_t *)run_alloc(run, proof_len))) return bail(smi_fail(ctx, SMI_ERR_OOM, "alloc proof"));
     uint8_t *misc = (uint8_t *)run->d_misc;
     FsState *d_fs = (FsState *)(misc + ml.fs);
     uint64_t *d_alphas = (uint64_t *)(misc + ml.alphas);
@@ -335,8 +356,8 @@ static int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codew
     uint64_t cur_len = len;
     for (uint64_t r = 0; r < R; r++) {
         // leaf hashes + tree (src/fri.rs:118-127); power-of-two lengths never need padding
-        uint8_t *nodes = nullptr;
-        if (hipMalloc((void **)&nodes, (2 * cur_len - 1) * 32) != hipSuccess) return bail(smi_fail(ctx, SMI_ERR_OOM, "hipMalloc tree"));
+        uint8_t *nodes = (uint8_t *)run_alloc(run, (2 * cur_len - 1) * 32);
+        if (!nodes) return bail(smi_fail(ctx, SMI_ERR_OOM, "alloc tree"));
         run->trees.push_back(nodes);
         run->codewords.push_back(const_cast<uint32_t *>(cur));
         run->lens.push_back(cur_len);
@@ -346,10 +367,10 @@ static int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codew
         // push root, absorb, challenge (src/fri.rs:129-138)
         fs_round_kernel<<<1, 64, 0, ctx->stream>>>(d_fs, root, run->d_proof + off_roots + 33 * r, last ? nullptr : d_alphas + r);
         if (last) break;
-        uint32_t *next = nullptr;
-        if (hipMalloc((void **)&next, (cur_len / 2) * 4) != hipSuccess) return bail(smi_fail(ctx, SMI_ERR_OOM, "hipMalloc codeword"));
+        uint32_t *next = (uint32_t *)run_alloc(run, (cur_len / 2) * 4);
+        if (!next) return bail(smi_fail(ctx, SMI_ERR_OOM, "alloc codeword"));
         if ((rc = launch_fold(ctx, cur, cur_len, d_alphas + r, offset, omega, next)) != SMI_OK) {
-            hipFree(next);
+            if (!run->arena) (void)hipFree(next);
             return bail(rc);
         }
         cur = next;
@@ -383,8 +404,8 @@ static int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codew
     if (hipMemcpyAsync(proof.data(), run->d_proof, proof_len, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
         return bail(smi_fail(ctx, SMI_ERR_HIP, "copy proof"));
     std::vector<uint64_t> alphas(R), top(t + 1);
-    hipMemcpyAsync(alphas.data(), d_alphas, 8 * (R - 1), hipMemcpyDeviceToHost, ctx->stream);
-    if (do_query) hipMemcpyAsync(top.data(), d_top, 8 * t, hipMemcpyDeviceToHost, ctx->stream);
+    (void)hipMemcpyAsync(alphas.data(), d_alphas, 8 * (R - 1), hipMemcpyDeviceToHost, ctx->stream);
+    if (do_query) (void)hipMemcpyAsync(top.data(), d_top, 8 * t, hipMemcpyDeviceToHost, ctx->stream);
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return bail(smi_hip_fail(ctx, e, "fri sync"));
 
@@ -411,7 +432,7 @@ int smi_dev_fri_prove(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_co
                       size_t *proof_len, uint64_t *top_indices, smi_fri_run **run) {
     if (!ctx || !cfg || !d_codeword || !proof || !proof_len) return SMI_ERR_BAD_ARG;
     std::vector<uint8_t> bytes;
-    SMI_TRY(fri_run(ctx, cfg, d_codeword, len, true, run, &bytes, top_indices, nullptr, nullptr, nullptr, nullptr));
+    SMI_TRY(fri_run(ctx, cfg, d_codeword, len, true, true, run, &bytes, top_indices, nullptr, nullptr, nullptr, nullptr));
     *proof = (uint8_t *)malloc(bytes.size() ? bytes.size() : 1);
     if (!*proof) return smi_fail(ctx, SMI_ERR_OOM, "malloc proof");
     memcpy(*proof, bytes.data(), bytes.size());
@@ -436,8 +457,8 @@ int smi_fri_prove(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint64_t *codeword
     uint32_t *d_cw = nullptr;
     int rc = upload_codeword(ctx, codeword, len, &d_cw);
     if (rc == SMI_OK) rc = smi_dev_fri_prove(ctx, cfg, d_cw, len, proof, proof_len, top_indices, nullptr);
-    hipStreamSynchronize(ctx->stream);
-    hipFree(d_cw);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_cw);
     return rc;
 }
 
@@ -449,13 +470,13 @@ int smi_fri_commit(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint64_t *codewor
     uint32_t *d_cw = nullptr;
     int rc = upload_codeword(ctx, codeword, len, &d_cw);
     smi_fri_run *r = nullptr;
-    if (rc == SMI_OK) rc = fri_run(ctx, cfg, d_cw, len, false, run ? &r : nullptr, nullptr, nullptr, roots, alphas, last_codeword, last_len);
-    hipStreamSynchronize(ctx->stream);
+    if (rc == SMI_OK) rc = fri_run(ctx, cfg, d_cw, len, false, true, run ? &r : nullptr, nullptr, nullptr, roots, alphas, last_codeword, last_len);
+    (void)hipStreamSynchronize(ctx->stream);
     if (rc == SMI_OK && run) {
         r->owns_first = true;  // the run keeps the uploaded codeword
         *run = r;
     } else {
-        hipFree(d_cw);
+        (void)hipFree(d_cw);
     }
     return rc;
 }

@@ -133,6 +133,10 @@ int launch_merkle(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_no
         uint32_t K = depth - lvl < KMAX ? depth - lvl : KMAX;
         const size_t threads = count >> K;
         const size_t lds = (size_t)(8u << K) * SMI_HASH_THREADS * sizeof(uint32_t);
+        // algorithmic bytes: inputs read once (4 B elements or 32 B digests), every produced digest written once
+        const double produced = from_elems ? (double)count * 2.0 - (double)(count >> K) : (double)count - (double)(count >> K);
+        ProfScope ps(ctx, from_elems ? "merkle_sub_kernel<leaves>" : "merkle_sub_kernel<digests>",
+                     (from_elems ? 4.0 : 32.0) * (double)count + 32.0 * produced);
         if (from_elems)
             merkle_sub_kernel<true><<<blocks_for(threads), SMI_HASH_THREADS, lds, ctx->stream>>>(d_elems, nodes, n, 0, count, K);
         else

@@ -13,6 +13,12 @@ struct ScaleEntry {
     uint32_t *lo, *hi;
 };
 
+struct ProfRec {
+    const char *name;
+    hipEvent_t e0, e1;
+    double bytes;
+};
+
 struct smi_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -26,6 +32,35 @@ struct smi_ctx {
     size_t tmp_bytes[4] = {0, 0, 0, 0};
     int *d_flag = nullptr;         // non-canonical input flag
     std::string err;
+    bool prof_on = false;
+    std::vector<ProfRec> prof;
+    // bump arena for the per-prove device buffers (trees, folded codewords, proof bytes):
+    // steady state does no hipMalloc/hipFree.  Overflow allocations are tracked and the
+    // arena is regrown to the high-water mark at the next reset.
+    uint8_t *arena = nullptr;
+    size_t arena_size = 0, arena_used = 0, arena_want = 0;
+    std::vector<void *> arena_overflow;
+};
+int arena_reset(smi_ctx *ctx);                       // syncs the stream if memory has to move
+void *arena_alloc(smi_ctx *ctx, size_t bytes);       // nullptr on OOM
+
+// HIP-event bracket around one kernel launch (no-ops unless profiling is enabled)
+struct ProfScope {
+    smi_ctx *ctx;
+    ProfRec r;
+    bool on;
+    ProfScope(smi_ctx *c, const char *name, double bytes) : ctx(c), on(c->prof_on) {
+        if (!on) return;
+        r.name = name;
+        r.bytes = bytes;
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(r.e0, ctx->stream);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(r.e1, ctx->stream);
+        ctx->prof.push_back(r);
+    }
 };
 
 struct smi_tree {

@@ -93,11 +93,22 @@ struct HipLauncher {
     smi_ctx *ctx;
     hipError_t err = hipSuccess;
     void small(const SmallArgs &a, uint32_t batch) {
+        ProfScope ps(ctx, "ntt_small_kernel", (4.0 * a.n_in + 4.0 * (1ull << a.L)) * batch);
         ntt_small_kernel<<<batch, SMI_NTT_THREADS, 0, ctx->stream>>>(a);
         note();
     }
     void pass(int logr, bool last, const PassArgs &a, uint32_t batch) {
         const dim3 grid(a.n_tiles, batch);
+        // algorithmic bytes of one pass: every point read once and written once (4 B each);
+        // the first pass of a zero-padded transform reads only its n_in real inputs
+        const double n = (double)(1ull << a.L);
+        const double bytes = ((a.flags & NTT_FIRST) ? 4.0 * a.n_in : 4.0 * n) * batch + 4.0 * n * batch;
+        static const char *names[5][2] = {{"ntt_pass_kernel<6,false>", "ntt_pass_kernel<6,true>"},
+                                          {"ntt_pass_kernel<7,false>", "ntt_pass_kernel<7,true>"},
+                                          {"ntt_pass_kernel<8,false>", "ntt_pass_kernel<8,true>"},
+                                          {"ntt_pass_kernel<9,false>", "ntt_pass_kernel<9,true>"},
+                                          {"ntt_pass_kernel<10,false>", "ntt_pass_kernel<10,true>"}};
+        ProfScope ps(ctx, names[logr - 6][last ? 1 : 0], bytes);
 #define CASE(LR)                                                                                  \
     case LR:                                                                                      \
         if (last) ntt_pass_kernel<LR, true><<<grid, SMI_NTT_THREADS, 0, ctx->stream>>>(a);        \

@@ -1,0 +1,132 @@
+// stark.hip -- the build-defined composition "trace -> LDE -> commit -> combine -> Fri::prove".
+//
+// The reference has no prover that connects Trace to Fri::prove (no AIR, no
+// quotient, no LDE function).  This file composes the reference's primitives in the way
+// SURVEY 8(d) cfg5 specifies, entirely on the device:
+//   1. per-column iNTT on the trace domain + coset NTT on the blowup domain (ntt.hip);
+//   2. one Merkle tree per column, one element per leaf -- the reference's only leaf rule
+//      (src/fri.rs:118-121);
+//   3. a fresh FiatShamir absorbs the column roots in order and draws one weight per column
+//      (src/fiat_shamir.rs:15-25); codeword = sum_c weight_c * column_c;
+//   4. Fri::prove semantics on that codeword (src/fri.rs:250-311), fresh FiatShamir as in the
+//      reference's own tests (src/fri.rs:543-547).
+#include <vector>
+
+#include "hash_core.h"
+#include "internal.h"
+
+int launch_merkle(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_nodes);
+int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, size_t len, bool do_query, bool reset_arena,
+            smi_fri_run **run_out, std::vector<uint8_t> *proof_host, uint64_t *top_host, uint8_t *roots_host,
+            uint64_t *alphas_host, uint64_t *last_host, size_t *last_len);
+
+// weights[c] = FiatShamir::challenge after absorbing roots[0..c] (unreduced u64)
+__global__ void fs_weights_kernel(const uint8_t *const *root_ptrs, uint32_t n, uint64_t *weights) {
+    if (threadIdx.x || blockIdx.x) return;
+    hashc::State st;
+    hashc::init(st);
+    for (uint32_t c = 0; c < n; c++) {
+        const uint32_t *root = (const uint32_t *)root_ptrs[c];
+        uint32_t m[8];
+        for (int i = 0; i < 8; i++) m[i] = root[i];
+        hashc::absorb_chunk32(st, m);
+        hashc::State ch = st;
+        for (int k = 0; k < 8; k++) hashc::mix(ch);
+        uint32_t d[8];
+        hashc::to_words(ch, d);
+        weights[c] = (uint64_t)d[0] | ((uint64_t)d[1] << 32);
+    }
+}
+
+// out[i] = sum_c (weights[c] mod p) * cols[c*stride + i]      HBM-bound: 4*(n_cols+1) B per element
+__global__ __launch_bounds__(256) void combine_columns_kernel(const uint32_t *__restrict__ cols, uint32_t n_cols, size_t len,
+                                                              size_t stride, const uint64_t *__restrict__ weights, Fp F,
+                                                              uint32_t *__restrict__ out) {
+    __shared__ uint32_t w_m[64];
+    if (threadIdx.x < n_cols) w_m[threadIdx.x] = to_mont((uint32_t)(weights[threadIdx.x] % F.p), F);
+    __syncthreads();
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += step) {
+        uint32_t acc = 0;
+        for (uint32_t c = 0; c < n_cols; c++) acc = fp_add(acc, mont_mul(cols[c * stride + i], w_m[c], F), F.p);
+        out[i] = acc;
+    }
+}
+
+int smi_dev_combine_columns(smi_ctx *ctx, const uint32_t *d_cols, uint32_t n_cols, size_t len, size_t stride,
+                            const uint64_t *d_weights, uint32_t *d_out) {
+    if (!ctx || !d_cols || !d_weights || !d_out || !n_cols) return SMI_ERR_BAD_ARG;
+    if (n_cols > 64) return smi_fail(ctx, SMI_ERR_BAD_ARG, "combine: at most 64 columns per call");
+    if (!len) return SMI_OK;
+    size_t grid = (len + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    ProfScope ps(ctx, "combine_columns_kernel", 4.0 * (n_cols + 1.0) * (double)len);
+    combine_columns_kernel<<<(uint32_t)grid, 256, 0, ctx->stream>>>(d_cols, n_cols, len, stride, d_weights, ctx->fs.F, d_out);
+    HIP_TRY(ctx, hipGetLastError());
+    return SMI_OK;
+}
+
+int smi_dev_stark_prove(smi_ctx *ctx, const smi_stark_cfg *cfg, const uint32_t *d_trace_cols, uint8_t *column_roots,
+                        uint8_t **proof, size_t *proof_len, uint64_t *top_indices, double *stage_ms) {
+    if (!ctx || !cfg || !d_trace_cols || !proof || !proof_len) return SMI_ERR_BAD_ARG;
+    const uint32_t W = cfg->n_cols, log_N = cfg->log_n + cfg->log_blowup;
+    if (!W || W > 64) return smi_fail(ctx, SMI_ERR_BAD_ARG, "stark_prove: 1..64 columns");
+    if (cfg->log_blowup < 2) return smi_fail(ctx, SMI_ERR_EXPANSION_TOO_SMALL, nullptr);  // Fri::new, src/fri.rs:45
+    if (log_N > ctx->fs.K)
+        return smi_fail(ctx, ctx->fs.F.p == 998244353u ? SMI_ERR_ROOT_TOO_LARGE : SMI_ERR_UNSUPPORTED_PRIME, "LDE domain too large");
+    const size_t N = (size_t)1 << log_N;
+    SMI_TRY(arena_reset(ctx));
+    hipEvent_t ev[5];
+    const bool timed = stage_ms != nullptr;
+    if (timed)
+        for (auto &e : ev) HIP_TRY(ctx, hipEventCreate(&e));
+    auto mark = [&](int i) { if (timed) (void)hipEventRecord(ev[i], ctx->stream); };
+
+    uint32_t *d_lde = (uint32_t *)arena_alloc(ctx, (size_t)W * N * 4);
+    uint32_t *d_cw = (uint32_t *)arena_alloc(ctx, N * 4);
+    uint64_t *d_weights = (uint64_t *)arena_alloc(ctx, 8 * W);
+    const uint8_t **d_rootp = (const uint8_t **)arena_alloc(ctx, sizeof(void *) * W);
+    if (!d_lde || !d_cw || !d_weights || !d_rootp) return smi_fail(ctx, SMI_ERR_OOM, "stark_prove: device memory");
+    std::vector<uint8_t *> trees(W);
+    std::vector<const uint8_t *> rootp(W);
+    for (uint32_t c = 0; c < W; c++) {
+        if (!(trees[c] = (uint8_t *)arena_alloc(ctx, (2 * N - 1) * 32))) return smi_fail(ctx, SMI_ERR_OOM, "stark_prove: tree memory");
+        rootp[c] = trees[c] + (2 * N - 2) * 32;
+    }
+    mark(0);
+    SMI_TRY(smi_dev_lde(ctx, d_trace_cols, W, cfg->log_n, cfg->log_blowup, cfg->trace_offset, cfg->lde_offset, d_lde));
+    mark(1);
+    for (uint32_t c = 0; c < W; c++) SMI_TRY(launch_merkle(ctx, d_lde + (size_t)c * N, N, trees[c]));
+    mark(2);
+    HIP_TRY(ctx, hipMemcpyAsync(d_rootp, rootp.data(), sizeof(void *) * W, hipMemcpyHostToDevice, ctx->stream));
+    fs_weights_kernel<<<1, 64, 0, ctx->stream>>>(d_rootp, W, d_weights);
+    HIP_TRY(ctx, hipGetLastError());
+    SMI_TRY(smi_dev_combine_columns(ctx, d_lde, W, N, N, d_weights, d_cw));
+    mark(3);
+    if (column_roots)
+        for (uint32_t c = 0; c < W; c++)
+            HIP_TRY(ctx, hipMemcpyAsync(column_roots + 32 * c, rootp[c], 32, hipMemcpyDeviceToHost, ctx->stream));
+    smi_fri_cfg fc;
+    fc.omega = h_root(ctx, log_N);
+    fc.offset = cfg->lde_offset;
+    fc.domain_length = N;
+    fc.expansion_factor = 1ull << cfg->log_blowup;
+    fc.num_colinearity_tests = cfg->num_colinearity_tests;
+    std::vector<uint8_t> bytes;
+    SMI_TRY(fri_run(ctx, &fc, d_cw, N, true, false, nullptr, &bytes, top_indices, nullptr, nullptr, nullptr, nullptr));
+    mark(4);
+    if (timed) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < 4; i++) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+            stage_ms[i] = ms;
+        }
+        for (auto &e : ev) (void)hipEventDestroy(e);
+    }
+    *proof = (uint8_t *)malloc(bytes.size() ? bytes.size() : 1);
+    if (!*proof) return smi_fail(ctx, SMI_ERR_OOM, "malloc proof");
+    memcpy(*proof, bytes.data(), bytes.size());
+    *proof_len = bytes.size();
+    return SMI_OK;
+}

@@ -53,6 +53,18 @@ class Engine:
     def sync(self):
         self._ck(self.L.smi_ctx_sync(self.h))
 
+    def profile(self, enable=True):
+        """Bracket every hot-path kernel launch with HIP events on the context's stream."""
+        self._ck(self.L.smi_ctx_profile(self.h, 1 if enable else 0))
+
+    def profile_read(self):
+        """-> {kernel name: {"launches", "total_ms", "alg_bytes"}} since the last read (synchronises)."""
+        arr = (_lib.KernelTime * 64)()
+        n = C.c_size_t()
+        self._ck(self.L.smi_ctx_profile_read(self.h, arr, 64, C.byref(n)))
+        return {arr[i].name.decode(): {"launches": int(arr[i].launches), "total_ms": float(arr[i].total_ms),
+                                       "alg_bytes": float(arr[i].alg_bytes)} for i in range(n.value)}
+
     @property
     def two_adicity(self):
         return int(self.L.smi_ctx_two_adicity(self.h))
@@ -245,6 +257,27 @@ class Engine:
         b = C.string_at(proof, plen.value)
         self.L.smi_free(proof)
         return b, [int(v) for v in top[:cfg.num_colinearity_tests]]
+
+    def dev_combine_columns(self, d_cols, n_cols, length, stride, d_weights, d_out):
+        self._ck(self.L.smi_dev_combine_columns(self.h, vp(d_cols), n_cols, length, stride, vp(d_weights), vp(d_out)))
+
+    def dev_stark_prove(self, d_trace_cols, n_cols, log_n, log_blowup, num_colinearity_tests, trace_offset=1,
+                        lde_offset=None, timed=False):
+        """Build-defined prove.  -> dict(column_roots, proof, top_indices[, stage_ms])."""
+        cfg = _lib.StarkCfg(log_n, log_blowup, n_cols, 0, trace_offset, self.g if lde_offset is None else lde_offset,
+                            num_colinearity_tests)
+        roots = np.zeros((n_cols, 32), dtype=np.uint8)
+        proof, plen = vp(), C.c_size_t()
+        top = np.zeros(max(num_colinearity_tests, 1), dtype=np.uint64)
+        stage = (C.c_double * 4)()
+        self._ck(self.L.smi_dev_stark_prove(self.h, C.byref(cfg), vp(d_trace_cols), roots.ctypes.data, C.byref(proof),
+                                            C.byref(plen), top.ctypes.data, stage if timed else None))
+        b = C.string_at(proof, plen.value)
+        self.L.smi_free(proof)
+        out = {"column_roots": roots, "proof": b, "top_indices": [int(v) for v in top[:num_colinearity_tests]]}
+        if timed:
+            out["stage_ms"] = dict(zip(("lde", "commit", "combine", "fri"), [float(x) for x in stage]))
+        return out
 
     def dev_fourstep_twiddle_pack(self, d_cols, d_send, log_r, log_c, c0, n_local_cols, n_ranks, inverse=False, offset=1):
         self._ck(self.L.smi_dev_fourstep_twiddle_pack(self.h, vp(d_cols), vp(d_send), log_r, log_c, c0, n_local_cols, n_ranks,

@@ -1,0 +1,185 @@
+"""GPU: device-resident pipeline (LDE -> commit -> combine -> Fri::prove), the four-step pieces
+at world size 1, and full-size property checks at BASELINE's sizes.  `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+P, G = 998244353, 3
+P2, G2 = 2013265921, 31
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import stark_rs_amd as s
+    e = s.Engine(P, G, 0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def eng2():
+    import stark_rs_amd as s
+    e = s.Engine(P2, G2, 0)
+    yield e
+    e.close()
+
+
+def _vals(o, seed, n, p=P):
+    return o.splitmix64(seed, n) % np.uint64(p)
+
+
+def _upload(eng, arr):
+    arr = np.ascontiguousarray(arr, dtype=np.uint64).reshape(-1)
+    d = eng.dev_alloc(arr.size * 4)
+    eng.dev_upload(arr, d)
+    return d
+
+
+@pytest.mark.parametrize("which", ["ref_prime", "second_prime"])
+def test_stark_prove_composition(eng, eng2, oracle, which):
+    """Every stage of the build-defined composition against the oracle: LDE, column roots,
+    Fiat-Shamir weights + combination (through the FRI round-0 root), and the oracle's
+    Fri::verify on the GPU proof."""
+    o = oracle
+    e, p, g = (eng, P, G) if which == "ref_prime" else (eng2, P2, G2)
+    logn, lb, W, t = 10, 3, 4, 8
+    n, N = 1 << logn, 1 << (logn + lb)
+    cols = np.stack([_vals(o, 0x5354524B00 + c, n, p) for c in range(W)])
+    d = _upload(e, cols)
+    res = e.dev_stark_prove(d, W, logn, lb, t, timed=True)
+    e.dev_free(d)
+    w, Wn = o.ff_prim_nth_root_g(n, p, g), o.ff_prim_nth_root_g(N, p, g)
+    lde = [o.fast_coset_ntt(o.fast_intt(cols[c], w, 1, p), N, Wn, g, p) for c in range(W)]
+    fs = o.FiatShamir()
+    weights = []
+    for c in range(W):
+        root = o.merkle_commit(o.leaf_hashes(lde[c]))
+        assert bytes(res["column_roots"][c]) == root
+        fs.absorb(root)
+        weights.append(fs.challenge() % p)
+    cw = np.zeros(N, dtype=object)
+    for c in range(W):
+        cw = (cw + lde[c].astype(object) * weights[c]) % p
+    cw = cw.astype(np.uint64)
+    cfg = o.fri_cfg(Wn, g, N, 1 << lb, t, p)
+    want_proof, want_top = o.fri_prove(cfg, cw)
+    assert res["top_indices"] == want_top
+    assert res["proof"] == want_proof
+    assert o.fri_verify(cfg, res["proof"]), o.fri_last_reject()
+    assert set(res["stage_ms"]) == {"lde", "commit", "combine", "fri"}
+
+
+def test_transpose_and_fourstep_world1(eng2, oracle):
+    import torch
+    from stark_rs_amd.fourstep import FourStepNTT, HipBackend
+    o = oracle
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 2 ** 31, (100, 333), dtype=np.int32)
+    x = torch.from_numpy(a).cuda()
+    y = torch.empty(333 * 100, dtype=torch.int32, device="cuda")
+    eng2.dev_transpose(x.data_ptr(), y.data_ptr(), 100, 333)
+    eng2.sync()
+    assert np.array_equal(y.cpu().numpy().reshape(333, 100), a.T)
+    for (lr, lc, offset, inverse) in [(8, 8, 1, False), (7, 9, 31, False), (9, 8, 1, True)]:
+        N = 1 << (lr + lc)
+        xs = _vals(o, 5, N, P2)
+        cols = xs.astype(np.uint32).reshape(1 << lr, 1 << lc).T.copy()      # column-major
+        t = torch.from_numpy(cols.reshape(-1).view(np.int32)).cuda()
+        fs = FourStepNTT(HipBackend(eng2), lr, lc, P2)
+        out = fs.forward(t, offset=offset, inverse=inverse)
+        eng2.sync()
+        got = out.cpu().numpy().view(np.uint32).reshape(1 << lc, 1 << lr).reshape(-1).astype(np.uint64)
+        w = o.ff_prim_nth_root_g(N, P2, G2)
+        want = o.fast_intt(xs, w, 1, P2) if inverse else o.fast_coset_ntt(xs, N, w, offset, P2)
+        assert np.array_equal(got, want)
+
+
+def test_cfg3_full_size_lde_and_commit_properties(eng, oracle):
+    """BASELINE configs[2]: 2^20-row x 4-column trace, blowup 8 (N = 2^23, the largest domain the
+    reference prime has) + Merkle commit.  Size-independent properties: the extension agrees with
+    the trace on the subgroup it extends, the op-for-op oracle's Polynomial::eval at sampled
+    points, interpolating the extension back gives a degree < n polynomial, and sampled Merkle
+    paths verify with the oracle's MerkleTree::verify."""
+    o = oracle
+    logn, lb, W = 20, 3, 4
+    n, N = 1 << logn, 1 << (logn + lb)
+    cols = np.stack([_vals(o, 0x5354524B00 + c, n) for c in range(W)])
+    d_in = _upload(eng, cols)
+    d_out = eng.dev_alloc(W * N * 4)
+    eng.dev_lde(d_in, W, logn, lb, d_out, 1, G)
+    lde = eng.dev_download(d_out, W * N).reshape(W, N)
+    w, Wn = o.ff_prim_nth_root(n), o.ff_prim_nth_root(N)
+    for c in (0, 3):
+        coeffs = eng.intt(cols[c], 1)
+        for k in (0, 1, 777777, N - 1):                                      # oracle eval.rs:6-14 at x_k
+            assert o.poly_eval(coeffs, o.ff_mul(G, o.ff_exp(Wn, k))) == int(lde[c, k])
+        back = eng.intt(lde[c], G)                                           # degree < n: high coefficients vanish
+        assert np.array_equal(back[:n], coeffs) and not back[n:].any()
+    # the same extension on offset 1 contains the trace itself at stride 8
+    eng.dev_lde(d_in, W, logn, lb, d_out, 1, 1)
+    plain = eng.dev_download(d_out, N)
+    assert np.array_equal(plain[::8], cols[0])
+    # commit column 0 of the coset extension; sampled openings verified by the oracle
+    d_nodes = eng.dev_alloc((2 * N - 1) * 32)
+    eng.dev_lde(d_in, W, logn, lb, d_out, 1, G)
+    eng.dev_merkle_build(d_out, N, d_nodes)
+    tree = eng.merkle_from_codeword(lde[0])
+    root = tree.root()
+    for i in (0, 1, 4242424, N - 1):
+        assert o.merkle_verify(o.hash_from_field_elements([int(lde[0, i])]), i, tree.open(i), root)
+    import ctypes as C
+    raw = np.zeros(32, dtype=np.uint8)
+    import stark_rs_amd._lib as L
+    # root produced by the device-resident build equals the host-buffer build
+    lib = L.lib()
+    top = eng.dev_alloc(32)
+    eng.sync()
+    import torch
+    t = torch.empty(8, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    # copy the last digest of d_nodes through the ABI's download path (as 8 u32 words)
+    words = eng.dev_download(d_nodes + (2 * N - 2) * 32, 8)
+    assert b"".join(int(v).to_bytes(4, "little") for v in words) == root
+    tree.free()
+    for ptr in (d_in, d_out, d_nodes, top):
+        eng.dev_free(ptr)
+
+
+def test_full_size_fri_prove_accepted_by_oracle_verify(eng, oracle):
+    """The parity-checked twin of BASELINE configs[4] on the reference prime: a 2^23-point
+    codeword of a degree < 2^20 polynomial, expansion 8, 32 colinearity tests -> 16 rounds, last
+    codeword 256.  The oracle's Fri::verify (src/fri.rs:313-504) must accept the GPU proof, and
+    reject it after a one-bit corruption."""
+    o = oracle
+    logn, lb, t = 20, 3, 32
+    N = 1 << (logn + lb)
+    Wn = o.ff_prim_nth_root(N)
+    coeffs = _vals(o, 99, 1 << logn)
+    codeword = eng.coset_ntt(coeffs, logn + lb, G)
+    cfg = eng.fri_cfg(Wn, G, N, 1 << lb, t)
+    assert eng.fri_num_rounds(cfg) == 16
+    proof, top = eng.fri_prove(cfg, codeword)
+    ocfg = o.fri_cfg(Wn, G, N, 1 << lb, t)
+    ok, values = o.fri_verify(ocfg, proof, want_values=True)
+    assert ok, o.fri_last_reject()
+    assert len(values) == 2 * t and all(int(codeword[i]) == v for i, v in values)
+    bad = bytearray(proof)
+    bad[len(bad) // 2] ^= 4
+    assert not o.fri_verify(ocfg, bytes(bad))
+
+
+def test_cfg5_shape_on_second_prime(eng2, oracle):
+    """BASELINE configs[4] shape (2^22 rows x 4 columns, blowup 8 -> 2^25 domain, 18 rounds) on the
+    second prime; accepted by the p-generic oracle's Fri::verify."""
+    o = oracle
+    logn, lb, W, t = 22, 3, 4, 32
+    n, N = 1 << logn, 1 << (logn + lb)
+    cols = np.stack([_vals(o, 0x5354524B00 + c, n, P2) for c in range(W)])
+    d = _upload(eng2, cols)
+    res = eng2.dev_stark_prove(d, W, logn, lb, t, timed=True)
+    eng2.dev_free(d)
+    Wn = o.ff_prim_nth_root_g(N, P2, G2)
+    cfg = o.fri_cfg(Wn, G2, N, 1 << lb, t, P2)
+    assert o.fri_num_rounds(cfg) == 18
+    assert o.fri_verify(cfg, res["proof"]), o.fri_last_reject()
