@@ -128,21 +128,11 @@ def test_cfg3_full_size_lde_and_commit_properties(eng, oracle):
     root = tree.root()
     for i in (0, 1, 4242424, N - 1):
         assert o.merkle_verify(o.hash_from_field_elements([int(lde[0, i])]), i, tree.open(i), root)
-    import ctypes as C
-    raw = np.zeros(32, dtype=np.uint8)
-    import stark_rs_amd._lib as L
     # root produced by the device-resident build equals the host-buffer build
-    lib = L.lib()
-    top = eng.dev_alloc(32)
-    eng.sync()
-    import torch
-    t = torch.empty(8, dtype=torch.int32, device="cuda")
-    torch.cuda.synchronize()
-    # copy the last digest of d_nodes through the ABI's download path (as 8 u32 words)
     words = eng.dev_download(d_nodes + (2 * N - 2) * 32, 8)
     assert b"".join(int(v).to_bytes(4, "little") for v in words) == root
     tree.free()
-    for ptr in (d_in, d_out, d_nodes, top):
+    for ptr in (d_in, d_out, d_nodes):
         eng.dev_free(ptr)
 
 
