@@ -74,6 +74,7 @@ extern "C" int emu_ntt(uint64_t p, uint64_t g, const uint32_t *in, uint32_t *out
         rq.pre_scale = offset % pp != 1;
         if (rq.pre_scale) {
             GeomSpec s2[2];
+            rq.q_plain = (uint32_t)(offset % pp);
             scale_table_specs(F, 1, (uint32_t)(offset % pp), L, s2);
             slo = fill(s2[0], F); shi = fill(s2[1], F);
         }
@@ -82,6 +83,7 @@ extern "C" int emu_ntt(uint64_t p, uint64_t g, const uint32_t *in, uint32_t *out
         const uint32_t ninv = host_powmod((uint32_t)((1ull << L) % pp), pp - 2, pp);
         const uint32_t q = host_mulmod((uint32_t)(post_scale % pp), host_powmod((uint32_t)(offset % pp), pp - 2, pp), pp);
         GeomSpec s2[2];
+        rq.q_plain = q;
         scale_table_specs(F, ninv, q, L, s2);
         slo = fill(s2[0], F); shi = fill(s2[1], F);
     }

@@ -147,11 +147,13 @@ int dev_ntt(smi_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint32_t log_n,
     rq.T = ctx_tables(ctx, inverse);
     if (!inverse) {
         rq.pre_scale = offset != 1;
+        rq.q_plain = (uint32_t)offset;
         if (rq.pre_scale) SMI_TRY(ctx_scale_tables(ctx, 1, (uint32_t)offset, log_n, &rq.S));
     } else {
         rq.post_scale = true;  // n^-1 * (post_scale/offset)^j
         const uint32_t ninv = h_inv(ctx, (uint32_t)(n % p));
         const uint32_t q = h_mul(ctx, (uint32_t)post_scale, h_inv(ctx, (uint32_t)offset));
+        rq.q_plain = q;
         SMI_TRY(ctx_scale_tables(ctx, ninv, q, log_n, &rq.S));
     }
     if (log_n > SMI_TILE_LOG) SMI_TRY(ctx_scratch(ctx, (size_t)batch << log_n, &rq.scratch));

@@ -53,14 +53,19 @@ struct PassArgs {
     uint32_t n_mid;    // digits strictly between first and last pass
     uint32_t mid_log[2];
     uint32_t n_tiles;  // grid.x
+    uint32_t pre_ratio_m;   // q^(T*B): step of the input coset scale between a thread's loads (Montgomery)
+    uint32_t post_ratio_m;  // q^(2^Sp): step of the output scale between a thread's stores (Montgomery)
 };
 
-// digit structure of the in-tile transform
+// digit structure of the in-tile transform.  s0 = 4 everywhere: in the store phase thread t owns
+// column w = t % W and the 16 positions loc = (t / W) + i * (256 / W), whose leading digit is i, so
+// its frequencies are k = i + 16 * krest -- consecutive, which lets inter-pass twiddles and coset
+// scales be running products instead of per-element table gathers.
 template <int LOGR> struct Steps;
-template <> struct Steps<6>  { enum { n = 2, s0 = 3, s1 = 3, s2 = 0 }; };
+template <> struct Steps<6>  { enum { n = 2, s0 = 4, s1 = 2, s2 = 0 }; };
 template <> struct Steps<7>  { enum { n = 2, s0 = 4, s1 = 3, s2 = 0 }; };
 template <> struct Steps<8>  { enum { n = 2, s0 = 4, s1 = 4, s2 = 0 }; };
-template <> struct Steps<9>  { enum { n = 3, s0 = 3, s1 = 3, s2 = 3 }; };
+template <> struct Steps<9>  { enum { n = 3, s0 = 4, s1 = 3, s2 = 2 }; };
 template <> struct Steps<10> { enum { n = 3, s0 = 4, s1 = 3, s2 = 3 }; };
 
 template <int S> SMI_HD constexpr uint32_t brev(uint32_t x) {
@@ -152,15 +157,23 @@ template <int LOGR, bool LAST> struct NttPass {
         const uint32_t *in = a.in + (uint64_t)batch * a.in_stride;
         if (!LAST) {
             const uint32_t blog = a.L - a.Sp - LOGR;
+            // thread-constant column w; rows j = j0 + i*T.  The coset scale q^g of input index
+            // g = g0 + i*(T<<blog) advances by the constant pre_ratio = q^(T<<blog).
+            const uint32_t w = tid & (W - 1), j0 = tid >> LOGW;
+            const uint64_t g0 = t.in_base + ((uint64_t)j0 << blog) + w;
+            uint32_t sc = 0;
+            if (a.flags & NTT_PRE_SCALE) sc = g0 < a.n_in ? two_level(a.S.lo, a.S.hi, a.S.h, (uint32_t)g0, a.F) : 0u;
 #pragma unroll
             for (int i = 0; i < V; i++) {
-                const uint32_t idx = tid + i * SMI_NTT_THREADS;
-                const uint32_t w = idx & (W - 1), j = idx >> LOGW;
-                const uint64_t g = t.in_base + ((uint64_t)j << blog) + w;
+                const uint32_t j = j0 + i * (SMI_NTT_THREADS >> LOGW);
+                const uint64_t g = g0 + ((uint64_t)(i * (SMI_NTT_THREADS >> LOGW)) << blog);
                 uint32_t v;
                 if (a.flags & NTT_FIRST) {
                     v = g < a.n_in ? in[g] : 0u;
-                    if ((a.flags & NTT_PRE_SCALE) && v) v = mont_mul(v, two_level(a.S.lo, a.S.hi, a.S.h, (uint32_t)g, a.F), a.F);
+                    if (a.flags & NTT_PRE_SCALE) {
+                        v = mont_mul(v, sc, a.F);
+                        sc = mont_mul(sc, a.pre_ratio_m, a.F);
+                    }
                 } else {
                     v = in[g];
                 }
@@ -220,25 +233,47 @@ template <int LOGR, bool LAST> struct NttPass {
         }
     }
 
+    // rest digits of a position (everything below the leading radix-16 digit) -> their weight in k
+    static SMI_HD uint32_t rest_to_k(uint32_t loc0) {
+        if (St::n == 2) return loc0;  // k1
+        const uint32_t k1 = loc0 >> St::s2, k2 = loc0 & ((1u << St::s2) - 1u);
+        return k1 | (k2 << St::s1);
+    }
+
     static SMI_HD void store(const PassArgs &a, const TileId &t, uint32_t batch, const uint32_t *tile, uint32_t tid) {
         uint32_t *out = a.out + (uint64_t)batch * a.out_stride;
         const uint32_t mlog = a.L - a.Sp;  // log2 m (sub-problem size of this pass)
+        // thread-constant column w; positions loc = loc0 + i*T have leading digit i, so the
+        // frequencies are k = i + 16*krest, i = 0..15.
+        const uint32_t w = tid & (W - 1), loc0 = tid >> LOGW;
+        const uint32_t krest = rest_to_k(loc0);
+        if (!LAST) {
+            // inter-pass twiddle w_m^(k*b) = g^k with g = w_m^b = Wmax^(b << (K - mlog)):
+            // one table lookup per thread, then a running product over the 16 consecutive k.
+            const uint32_t b = t.b0 + w;
+            const uint32_t g = two_level(a.T.lo, a.T.hi, a.T.h, b << (a.T.K - mlog), a.F);
+            uint32_t cur = mont_pow(g, (uint64_t)krest << 4, a.F);
 #pragma unroll
-        for (int i = 0; i < V; i++) {
-            const uint32_t idx = tid + i * SMI_NTT_THREADS;
-            const uint32_t w = idx & (W - 1), loc = idx >> LOGW;
-            const uint32_t k = loc_to_k(loc);
-            uint32_t v = tile[loc * WP + w];
-            if (!LAST) {
-                const uint32_t b = t.b0 + w;
-                // inter-pass twiddle w_m^(k*b) = Wmax^((k*b) << (K - mlog))
-                const uint32_t e = (k * b) << (a.T.K - mlog);
-                if (e) v = mont_mul(v, two_level(a.T.lo, a.T.hi, a.T.h, e, a.F), a.F);
+            for (int i = 0; i < V; i++) {
+                const uint32_t loc = loc0 + i * (SMI_NTT_THREADS >> LOGW);
+                const uint32_t k = (uint32_t)i + (krest << 4);
+                const uint32_t v = mont_mul(tile[loc * WP + w], cur, a.F);
+                cur = mont_mul(cur, g, a.F);
                 out[t.out_base + ((uint64_t)k << (mlog - LOGR)) + w] = v;
-            } else {
-                const uint64_t kn = ((uint64_t)k << a.Sp) + t.out_base + w;
-                if (a.flags & NTT_POST_SCALE) v = mont_mul(v, two_level(a.S.lo, a.S.hi, a.S.h, (uint32_t)kn, a.F), a.F);
-                out[kn] = v;
+            }
+        } else {
+            const uint64_t kn0 = ((uint64_t)(krest << 4) << a.Sp) + t.out_base + w;
+            uint32_t sc = 0;
+            if (a.flags & NTT_POST_SCALE) sc = two_level(a.S.lo, a.S.hi, a.S.h, (uint32_t)kn0, a.F);
+#pragma unroll
+            for (int i = 0; i < V; i++) {
+                const uint32_t loc = loc0 + i * (SMI_NTT_THREADS >> LOGW);
+                uint32_t v = tile[loc * WP + w];
+                if (a.flags & NTT_POST_SCALE) {
+                    v = mont_mul(v, sc, a.F);
+                    sc = mont_mul(sc, a.post_ratio_m, a.F);
+                }
+                out[kn0 + ((uint64_t)i << a.Sp)] = v;
             }
         }
     }

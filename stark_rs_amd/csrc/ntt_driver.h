@@ -17,6 +17,7 @@ struct NttRequest {
     ScaleTables S;
     bool pre_scale;      // multiply input i by S(i)   (coset shift of a forward transform)
     bool post_scale;     // multiply output k by S(k)  (n^-1 * offset^-k of an inverse transform)
+    uint32_t q_plain;    // ratio of the scale sequence S(i) = c * q^i (plain form)
 };
 
 // Launcher concept:
@@ -50,6 +51,13 @@ template <class Launcher> inline void ntt_run(Launcher &ln, const NttRequest &rq
         a.n_mid = (uint32_t)(pl.np - 2);
         for (int d = 0; d < pl.np - 2; d++) a.mid_log[d] = (uint32_t)pl.logr[1 + d];
         a.n_tiles = (uint32_t)(n >> SMI_TILE_LOG);
+        {   // steps of the running-product scales (see NttPass::load / store)
+            const uint32_t logw = SMI_TILE_LOG - (uint32_t)pl.logr[p], blog = rq.L - consumed - (uint32_t)pl.logr[p];
+            const uint64_t pre_step = (uint64_t)(SMI_NTT_THREADS >> logw) << blog;
+            const uint32_t pr = host_powmod(rq.q_plain, pre_step, rq.F.p), po = host_powmod(rq.q_plain, 1ull << consumed, rq.F.p);
+            a.pre_ratio_m = (uint32_t)(((uint64_t)pr << 32) % rq.F.p);
+            a.post_ratio_m = (uint32_t)(((uint64_t)po << 32) % rq.F.p);
+        }
         ln.pass(pl.logr[p], last, a, rq.batch);
         consumed += (uint32_t)pl.logr[p];
     }
