@@ -74,7 +74,7 @@ int smi_ctx_create(uint64_t p, uint64_t g, int device, smi_ctx **out) {
             GeomSpec sp[3];
             ntt_table_specs(ctx->fs, dir, sp);
             for (int k = 0; k < 3 && rc == SMI_OK; k++) {
-                if (hipMalloc((void **)&ctx->d_tab[dir][k], (size_t)sp[k].count * 4) != hipSuccess) { rc = SMI_ERR_OOM; break; }
+                if (hipMalloc((void **)&ctx->d_tab[dir][k], ((size_t)sp[k].count * 4) << sp[k].pair) != hipSuccess) { rc = SMI_ERR_OOM; break; }
                 rc = launch_geom_table(ctx, sp[k], ctx->d_tab[dir][k]);
             }
         }
@@ -95,6 +95,7 @@ void smi_ctx_destroy(smi_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (int d = 0; d < 2; d++)
         for (int k = 0; k < 3; k++) (void)hipFree(ctx->d_tab[d][k]);
+    for (PassTable &t : ctx->pass_tables) (void)hipFree(t.d);
     for (ScaleEntry &e : ctx->scale_cache) {
         (void)hipFree(e.lo);
         (void)hipFree(e.hi);
@@ -216,7 +217,7 @@ int ctx_scratch(smi_ctx *ctx, size_t elems, uint32_t **out) {
 }
 NttTables ctx_tables(const smi_ctx *ctx, int inverse) {
     const int d = inverse ? 1 : 0;
-    return NttTables{ctx->d_tab[d][0], ctx->d_tab[d][1], ctx->d_tab[d][2], ctx->fs.K, ntt_table_h(ctx->fs.K)};
+    return NttTables{(const Tw2 *)ctx->d_tab[d][0], ctx->d_tab[d][1], ctx->d_tab[d][2], ctx->fs.K, ntt_table_h(ctx->fs.K)};
 }
 int ctx_scale_tables(smi_ctx *ctx, uint32_t c_plain, uint32_t q_plain, uint32_t L, ScaleTables *out) {
     for (const ScaleEntry &e : ctx->scale_cache)

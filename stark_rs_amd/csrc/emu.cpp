@@ -13,14 +13,19 @@
 namespace {
 
 std::vector<uint32_t> fill(const GeomSpec &s, const Fp &F) {
-    std::vector<uint32_t> t(s.count);
-    for (uint32_t i = 0; i < s.count; i++) t[i] = geom_entry(s.c_m, s.q_m, i, s.stride, F);
+    std::vector<uint32_t> t((size_t)s.count << s.pair);
+    for (uint32_t i = 0; i < s.count; i++) {
+        const uint32_t v = geom_entry(s.c_m, s.q_m, i, s.stride, F);
+        if (s.pair) { t[2 * i] = v; t[2 * i + 1] = v * F.pinv; }
+        else t[i] = v;
+    }
     return t;
 }
 
 template <int LOGR, bool LAST> void emu_pass(const PassArgs &a, uint32_t batch) {
     typedef NttPass<LOGR, LAST> NP;
-    std::vector<uint32_t> tile(NP::R * NP::WP), tw(NP::R);
+    std::vector<uint32_t> tile(NP::R * NP::WP);
+    std::vector<Tw2> tw(NP::R);
     for (uint32_t b = 0; b < batch; b++)
         for (uint32_t blk = 0; blk < a.n_tiles; blk++) {
             typename NP::TileId t = NP::tile_id(a, blk);
@@ -34,6 +39,14 @@ template <int LOGR, bool LAST> void emu_pass(const PassArgs &a, uint32_t batch) 
 }
 
 struct EmuLauncher {
+    Fp F;
+    NttTables T;
+    std::vector<std::vector<Tw2>> tabs;
+    const Tw2 *pass_table(uint32_t mlog, uint32_t logr) {
+        tabs.emplace_back((size_t)1 << mlog);
+        for (uint32_t i = 0; i < (1u << mlog); i++) tabs.back()[i] = pass_table_entry(i, mlog, logr, T, F);
+        return tabs.back().data();
+    }
     void small(const SmallArgs &a, uint32_t batch) {
         std::vector<uint32_t> buf(1u << a.L);
         for (uint32_t b = 0; b < batch; b++) {
@@ -67,7 +80,7 @@ extern "C" int emu_ntt(uint64_t p, uint64_t g, const uint32_t *in, uint32_t *out
     std::vector<uint32_t> tw10 = fill(sp[0], F), lo = fill(sp[1], F), hi = fill(sp[2], F);
     NttRequest rq;
     memset(&rq, 0, sizeof rq);
-    rq.T = NttTables{tw10.data(), lo.data(), hi.data(), fs.K, ntt_table_h(fs.K)};
+    rq.T = NttTables{(const Tw2 *)tw10.data(), lo.data(), hi.data(), fs.K, ntt_table_h(fs.K)};
     std::vector<uint32_t> slo, shi;
     const uint32_t pp = F.p;
     if (!inverse) {
@@ -92,6 +105,8 @@ extern "C" int emu_ntt(uint64_t p, uint64_t g, const uint32_t *in, uint32_t *out
     rq.in = in; rq.out = out; rq.scratch = scratch.data();
     rq.L = L; rq.n_in = n_in; rq.batch = batch; rq.in_stride = in_stride; rq.out_stride = out_stride; rq.F = F;
     EmuLauncher ln;
+    ln.F = F;
+    ln.T = rq.T;
     ntt_run(ln, rq);
     return 0;
 }

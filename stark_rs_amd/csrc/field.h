@@ -30,19 +30,39 @@ SMI_HD uint32_t fp_add(uint32_t a, uint32_t b, uint32_t p) {
     return s >= p ? s - p : s;
 }
 SMI_HD uint32_t fp_sub(uint32_t a, uint32_t b, uint32_t p) {
-    uint32_t d = a - b;
-    return a < b ? d + p : d;
+    const uint32_t d = a - b;   // wraps iff a < b, and then d + p wraps back into [0,p)
+    return d < d + p ? d : d + p;
 }
 SMI_HD uint32_t fp_neg(uint32_t a, uint32_t p) { return a ? p - a : 0; }
 
+SMI_HD uint32_t umulhi32(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+SMI_HD uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
 // a*b*R^-1 mod p for a*b < p*2^32 (e.g. a < p, b arbitrary u32).  Result in [0,p).
+// t = a*b, m = lo(t)*p^-1 mod 2^32; t - m*p is a multiple of 2^32 and (t - m*p)/2^32 =
+// hi(t) - hi(m*p) lies in (-p, p) -- the low words cancel exactly.  v_mul_lo/hi_u32 issue at the
+// full integer VALU rate on gfx950 (measured, tools/ubench_valu.hip) while v_mad_u64_u32 costs
+// ~2.5 slots, so the 64-bit product is spelled as a lo/hi pair; the final correction is the
+// 3-op min(r, r+p) form (r+p wraps back into [0,p) exactly when r is negative).
 SMI_HD uint32_t mont_mul(uint32_t a, uint32_t b, const Fp &F) {
-    uint64_t t = (uint64_t)a * b;
-    uint32_t m = (uint32_t)t * F.pinv;
-    uint32_t u = (uint32_t)(((uint64_t)m * F.p) >> 32);
-    uint32_t hi = (uint32_t)(t >> 32);
-    uint32_t r = hi - u;           // low words of t and m*p are equal: no borrow from below
-    return hi < u ? r + F.p : r;
+    const uint32_t lo = a * b, hi = umulhi32(a, b);
+    const uint32_t u = umulhi32(lo * F.pinv, F.p);
+    const uint32_t r = hi - u;
+    return umin32(r, r + F.p);
+}
+// Same product for a multiplicand b that comes with its companion bq = b * p^-1 mod 2^32
+// (twiddle tables store the pair): one multiply fewer on the dependent chain.
+SMI_HD uint32_t mont_mul_c(uint32_t a, uint32_t b, uint32_t bq, const Fp &F) {
+    const uint32_t hi = umulhi32(a, b);
+    const uint32_t u = umulhi32(a * bq, F.p);
+    const uint32_t r = hi - u;
+    return umin32(r, r + F.p);
 }
 SMI_HD uint32_t to_mont(uint32_t a, const Fp &F) { return mont_mul(a, F.r2, F); }
 SMI_HD uint32_t from_mont(uint32_t a, const Fp &F) { return mont_mul(a, 1u, F); }

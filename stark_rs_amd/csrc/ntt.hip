@@ -12,7 +12,7 @@ template <int LOGR, bool LAST>
 __global__ __launch_bounds__(SMI_NTT_THREADS) void ntt_pass_kernel(const PassArgs a) {
     typedef NttPass<LOGR, LAST> NP;
     __shared__ uint32_t tile[NP::R * NP::WP];
-    __shared__ uint32_t tw[NP::R];
+    __shared__ Tw2 tw[NP::R];
     const uint32_t tid = threadIdx.x, batch = blockIdx.y;
     const typename NP::TileId t = NP::tile_id(a, blockIdx.x);
     NP::load_tw(a, tw, tid);
@@ -43,7 +43,19 @@ __global__ __launch_bounds__(SMI_NTT_THREADS) void ntt_small_kernel(const SmallA
 
 __global__ void geom_table_kernel(uint32_t *out, GeomSpec s, Fp F) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < s.count) out[i] = geom_entry(s.c_m, s.q_m, i, s.stride, F);
+    if (i >= s.count) return;
+    const uint32_t v = geom_entry(s.c_m, s.q_m, i, s.stride, F);
+    if (s.pair) {
+        out[2 * i] = v;
+        out[2 * i + 1] = v * F.pinv;
+    } else {
+        out[i] = v;
+    }
+}
+
+__global__ void pass_table_kernel(Tw2 *out, uint32_t mlog, uint32_t logr, NttTables T, Fp F) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (1u << mlog)) out[i] = pass_table_entry(i, mlog, logr, T, F);
 }
 
 // u64 (reference wire width, src/stream.rs:45) <-> u32 device residues
@@ -118,6 +130,21 @@ struct HipLauncher {
 #undef CASE
         note();
     }
+    int inverse = 0;
+    const Tw2 *pass_table(uint32_t mlog, uint32_t logr) {
+        for (const PassTable &t : ctx->pass_tables)
+            if (t.inverse == inverse && t.mlog == mlog && t.logr == logr) return t.d;
+        if (mlog > 20) return nullptr;  // keep tables L2-sized; larger passes use the running product
+        PassTable t{inverse, mlog, logr, nullptr};
+        if (hipMalloc((void **)&t.d, sizeof(Tw2) << mlog) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        pass_table_kernel<<<((1u << mlog) + 255) / 256, 256, 0, ctx->stream>>>(t.d, mlog, logr, ctx_tables(ctx, inverse), ctx->fs.F);
+        note();
+        ctx->pass_tables.push_back(t);
+        return t.d;
+    }
     void note() {
         hipError_t e = hipGetLastError();
         if (err == hipSuccess) err = e;
@@ -158,6 +185,7 @@ int dev_ntt(smi_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint32_t log_n,
     }
     if (log_n > SMI_TILE_LOG) SMI_TRY(ctx_scratch(ctx, (size_t)batch << log_n, &rq.scratch));
     HipLauncher ln{ctx};
+    ln.inverse = inverse ? 1 : 0;
     ntt_run(ln, rq);
     if (ln.err != hipSuccess) return smi_hip_fail(ctx, ln.err, "ntt kernel launch");
     return SMI_OK;

@@ -26,8 +26,13 @@
 #define SMI_NTT_THREADS 256
 #define SMI_TW_LOG 10   // in-tile twiddle table: w_1024^j
 
+// A table twiddle with its Montgomery companion q = w * p^-1 mod 2^32 (see mont_mul_c).
+struct alignas(8) Tw2 {
+    uint32_t w, q;
+};
+
 struct NttTables {        // per (prime, direction); all values in Montgomery form
-    const uint32_t *tw10; // w_1024^j, j < 1024
+    const Tw2 *tw10;      // w_1024^j, j < 1024
     const uint32_t *lo;   // W^e,          e < 2^h      (W = primitive 2^K-th root for this direction)
     const uint32_t *hi;   // W^(e * 2^h),  e < 2^(K-h)
     uint32_t K, h;
@@ -53,6 +58,7 @@ struct PassArgs {
     uint32_t n_mid;    // digits strictly between first and last pass
     uint32_t mid_log[2];
     uint32_t n_tiles;  // grid.x
+    const Tw2 *ptab;        // inter-pass twiddles w_m^(k*b) at [k*B + b] for passes after the first (else null)
     uint32_t pre_ratio_m;   // q^(T*B): step of the input coset scale between a thread's loads (Montgomery)
     uint32_t post_ratio_m;  // q^(2^Sp): step of the output scale between a thread's stores (Montgomery)
 };
@@ -88,7 +94,7 @@ SMI_HD uint32_t two_level(const uint32_t *lo, const uint32_t *hi, uint32_t h, ui
 
 // S-stage radix-2 DIF on 2^S registers; x[brev(k)] = X_k on return.  cw = w_R^j table in
 // LDS, croot_shift = LOGR - S so that w_r^j = cw[j << croot_shift].
-template <int S> SMI_HD void dft_regs(uint32_t (&x)[1 << S], const uint32_t *cw, int croot_shift, const Fp &F) {
+template <int S> SMI_HD void dft_regs(uint32_t (&x)[1 << S], const Tw2 *cw, int croot_shift, const Fp &F) {
 #pragma unroll
     for (int s = 0; s < S; s++) {
         const int half = (1 << S) >> (s + 1);
@@ -100,7 +106,11 @@ template <int S> SMI_HD void dft_regs(uint32_t (&x)[1 << S], const uint32_t *cw,
             x[i] = fp_add(u, v, F.p);
             uint32_t d = fp_sub(u, v, F.p);
             const int e = (i & (half - 1)) << s;  // w_{2half}^pos = w_r^(pos << s)
-            x[j] = e ? mont_mul(d, cw[e << croot_shift], F) : d;
+            if (e) {
+                const Tw2 c = cw[e << croot_shift];
+                d = mont_mul_c(d, c.w, c.q, F);
+            }
+            x[j] = d;
         }
     }
 }
@@ -145,7 +155,7 @@ template <int LOGR, bool LAST> struct NttPass {
         return t;
     }
 
-    static SMI_HD void load_tw(const PassArgs &a, uint32_t *tw, uint32_t tid) {
+    static SMI_HD void load_tw(const PassArgs &a, Tw2 *tw, uint32_t tid) {
 #pragma unroll
         for (int i = 0; i < (R + SMI_NTT_THREADS - 1) / SMI_NTT_THREADS; i++) {
             uint32_t j = tid + i * SMI_NTT_THREADS;
@@ -154,28 +164,26 @@ template <int LOGR, bool LAST> struct NttPass {
     }
 
     static SMI_HD void load(const PassArgs &a, const TileId &t, uint32_t batch, uint32_t *tile, uint32_t tid) {
-        const uint32_t *in = a.in + (uint64_t)batch * a.in_stride;
+        // wave-uniform base pointer + 32-bit per-lane offsets (tile offsets stay below 2^27 elements)
+        const uint32_t *in = a.in + (uint64_t)batch * a.in_stride + t.in_base;
         if (!LAST) {
             const uint32_t blog = a.L - a.Sp - LOGR;
             // thread-constant column w; rows j = j0 + i*T.  The coset scale q^g of input index
             // g = g0 + i*(T<<blog) advances by the constant pre_ratio = q^(T<<blog).
             const uint32_t w = tid & (W - 1), j0 = tid >> LOGW;
-            const uint64_t g0 = t.in_base + ((uint64_t)j0 << blog) + w;
+            const uint32_t o0 = (j0 << blog) + w;
+            // in_base == b0 in the first pass (one sub-problem), so g = b0 + offset is the natural index
+            const uint32_t lim = (a.flags & NTT_FIRST) ? (a.n_in > t.b0 ? a.n_in - t.b0 : 0u) : 0xFFFFFFFFu;
             uint32_t sc = 0;
-            if (a.flags & NTT_PRE_SCALE) sc = g0 < a.n_in ? two_level(a.S.lo, a.S.hi, a.S.h, (uint32_t)g0, a.F) : 0u;
+            if (a.flags & NTT_PRE_SCALE) sc = o0 < lim ? two_level(a.S.lo, a.S.hi, a.S.h, t.b0 + o0, a.F) : 0u;
 #pragma unroll
             for (int i = 0; i < V; i++) {
                 const uint32_t j = j0 + i * (SMI_NTT_THREADS >> LOGW);
-                const uint64_t g = g0 + ((uint64_t)(i * (SMI_NTT_THREADS >> LOGW)) << blog);
-                uint32_t v;
-                if (a.flags & NTT_FIRST) {
-                    v = g < a.n_in ? in[g] : 0u;
-                    if (a.flags & NTT_PRE_SCALE) {
-                        v = mont_mul(v, sc, a.F);
-                        sc = mont_mul(sc, a.pre_ratio_m, a.F);
-                    }
-                } else {
-                    v = in[g];
+                const uint32_t o = o0 + ((uint32_t)(i * (SMI_NTT_THREADS >> LOGW)) << blog);
+                uint32_t v = o < lim ? in[o] : 0u;
+                if (a.flags & NTT_PRE_SCALE) {
+                    v = mont_mul(v, sc, a.F);
+                    sc = mont_mul(sc, a.pre_ratio_m, a.F);
                 }
                 tile[j * WP + w] = v;
             }
@@ -185,14 +193,13 @@ template <int LOGR, bool LAST> struct NttPass {
             for (int i = 0; i < V; i++) {
                 const uint32_t idx = tid + i * SMI_NTT_THREADS;
                 const uint32_t j = idx & (R - 1), l = idx >> LOGR;
-                const uint64_t g = t.in_base + ((uint64_t)l << (arest_log + LOGR)) + j;
-                tile[j * WP + l] = in[g];
+                tile[j * WP + l] = in[(l << (arest_log + LOGR)) + j];
             }
         }
     }
 
     // One radix-2^S step on sub-blocks of 2^MLOG points (MLOG = log2 M of this step).
-    template <int S, int MLOG> static SMI_HD void step(const PassArgs &a, uint32_t *tile, const uint32_t *tw, uint32_t tid) {
+    template <int S, int MLOG> static SMI_HD void step(const PassArgs &a, uint32_t *tile, const Tw2 *tw, uint32_t tid) {
         enum { r = 1 << S, SUB = MLOG - S, NB = (SMI_TILE / r) / SMI_NTT_THREADS };
 #pragma unroll
         for (int bi = 0; bi < NB; bi++) {
@@ -207,14 +214,17 @@ template <int LOGR, bool LAST> struct NttPass {
 #pragma unroll
             for (int kk = 0; kk < r; kk++) {
                 uint32_t v = x[brev<S>(kk)];
-                if (SUB > 0 && kk) v = mont_mul(v, tw[((pos * kk) << (LOGR - MLOG)) & (R - 1)], a.F);
+                if (SUB > 0 && kk) {
+                    const Tw2 c = tw[((pos * kk) << (LOGR - MLOG)) & (R - 1)];
+                    v = mont_mul_c(v, c.w, c.q, a.F);
+                }
                 tile[(base + ((uint32_t)kk << SUB)) * WP + w] = v;
             }
         }
     }
 
     // step I of the in-tile transform (I < St::n)
-    template <int I> static SMI_HD void step_i(const PassArgs &a, uint32_t *tile, const uint32_t *tw, uint32_t tid) {
+    template <int I> static SMI_HD void step_i(const PassArgs &a, uint32_t *tile, const Tw2 *tw, uint32_t tid) {
         if constexpr (I == 0) step<St::s0, LOGR>(a, tile, tw, tid);
         else if constexpr (I == 1) step<St::s1, LOGR - St::s0>(a, tile, tw, tid);
         else if constexpr (I == 2 && St::n == 3) step<St::s2, LOGR - St::s0 - St::s1>(a, tile, tw, tid);
@@ -241,39 +251,56 @@ template <int LOGR, bool LAST> struct NttPass {
     }
 
     static SMI_HD void store(const PassArgs &a, const TileId &t, uint32_t batch, const uint32_t *tile, uint32_t tid) {
-        uint32_t *out = a.out + (uint64_t)batch * a.out_stride;
+        uint32_t *out = a.out + (uint64_t)batch * a.out_stride + t.out_base;
         const uint32_t mlog = a.L - a.Sp;  // log2 m (sub-problem size of this pass)
         // thread-constant column w; positions loc = loc0 + i*T have leading digit i, so the
         // frequencies are k = i + 16*krest, i = 0..15.
         const uint32_t w = tid & (W - 1), loc0 = tid >> LOGW;
         const uint32_t krest = rest_to_k(loc0);
         if (!LAST) {
-            // inter-pass twiddle w_m^(k*b) = g^k with g = w_m^b = Wmax^(b << (K - mlog)):
-            // one table lookup per thread, then a running product over the 16 consecutive k.
+            const uint32_t blog = mlog - LOGR;
             const uint32_t b = t.b0 + w;
-            const uint32_t g = two_level(a.T.lo, a.T.hi, a.T.h, b << (a.T.K - mlog), a.F);
-            uint32_t cur = mont_pow(g, (uint64_t)krest << 4, a.F);
+            const uint32_t o0 = ((krest << 4) << blog) + w;
+            if (a.ptab) {
+                // passes after the first: w_m^(k*b) from the (L2-resident) table of this pass,
+                // read with the same coalescing as the data
+                const Tw2 *tab = a.ptab + t.b0;
 #pragma unroll
-            for (int i = 0; i < V; i++) {
-                const uint32_t loc = loc0 + i * (SMI_NTT_THREADS >> LOGW);
-                const uint32_t k = (uint32_t)i + (krest << 4);
-                const uint32_t v = mont_mul(tile[loc * WP + w], cur, a.F);
-                cur = mont_mul(cur, g, a.F);
-                out[t.out_base + ((uint64_t)k << (mlog - LOGR)) + w] = v;
+                for (int i = 0; i < V; i++) {
+                    const uint32_t loc = loc0 + i * (SMI_NTT_THREADS >> LOGW);
+                    const uint32_t o = o0 + ((uint32_t)i << blog);
+                    const Tw2 c = tab[o];
+                    out[o] = mont_mul_c(tile[loc * WP + w], c.w, c.q, a.F);
+                }
+            } else {
+                // first pass (m = n: a table would double the traffic): w_m^(k*b) = g^k with
+                // g = w_m^b; two lookups per thread, then a running product over consecutive k.
+                const uint32_t sh = a.T.K - mlog;
+                const uint32_t g = two_level(a.T.lo, a.T.hi, a.T.h, b << sh, a.F);
+                const uint32_t gq = g * a.F.pinv;
+                uint32_t cur = two_level(a.T.lo, a.T.hi, a.T.h, (b * (krest << 4)) << sh, a.F);
+#pragma unroll
+                for (int i = 0; i < V; i++) {
+                    const uint32_t loc = loc0 + i * (SMI_NTT_THREADS >> LOGW);
+                    const uint32_t v = mont_mul(tile[loc * WP + w], cur, a.F);
+                    cur = mont_mul_c(cur, g, gq, a.F);
+                    out[o0 + ((uint32_t)i << blog)] = v;
+                }
             }
         } else {
-            const uint64_t kn0 = ((uint64_t)(krest << 4) << a.Sp) + t.out_base + w;
+            const uint32_t o0 = ((krest << 4) << a.Sp) + w;
             uint32_t sc = 0;
-            if (a.flags & NTT_POST_SCALE) sc = two_level(a.S.lo, a.S.hi, a.S.h, (uint32_t)kn0, a.F);
+            if (a.flags & NTT_POST_SCALE) sc = two_level(a.S.lo, a.S.hi, a.S.h, (uint32_t)t.out_base + o0, a.F);
+            const uint32_t rq = a.post_ratio_m * a.F.pinv;
 #pragma unroll
             for (int i = 0; i < V; i++) {
                 const uint32_t loc = loc0 + i * (SMI_NTT_THREADS >> LOGW);
                 uint32_t v = tile[loc * WP + w];
                 if (a.flags & NTT_POST_SCALE) {
                     v = mont_mul(v, sc, a.F);
-                    sc = mont_mul(sc, a.post_ratio_m, a.F);
+                    sc = mont_mul_c(sc, a.post_ratio_m, rq, a.F);
                 }
-                out[kn0 + ((uint64_t)i << a.Sp)] = v;
+                out[o0 + ((uint32_t)i << a.Sp)] = v;
             }
         }
     }

@@ -23,6 +23,7 @@ struct NttRequest {
 // Launcher concept:
 //   void small(const SmallArgs&, uint32_t batch);
 //   void pass(int logr, bool last, const PassArgs&, uint32_t batch);
+//   const Tw2 *pass_table(uint32_t mlog, uint32_t logr);   // w_m^(k*b) table (cached), or nullptr
 template <class Launcher> inline void ntt_run(Launcher &ln, const NttRequest &rq) {
     const NttPlan pl = ntt_make_plan(rq.L);
     if (pl.np == 0) {
@@ -51,6 +52,7 @@ template <class Launcher> inline void ntt_run(Launcher &ln, const NttRequest &rq
         a.n_mid = (uint32_t)(pl.np - 2);
         for (int d = 0; d < pl.np - 2; d++) a.mid_log[d] = (uint32_t)pl.logr[1 + d];
         a.n_tiles = (uint32_t)(n >> SMI_TILE_LOG);
+        a.ptab = (!first && !last) ? ln.pass_table(rq.L - consumed, (uint32_t)pl.logr[p]) : nullptr;
         {   // steps of the running-product scales (see NttPass::load / store)
             const uint32_t logw = SMI_TILE_LOG - (uint32_t)pl.logr[p], blog = rq.L - consumed - (uint32_t)pl.logr[p];
             const uint64_t pre_step = (uint64_t)(SMI_NTT_THREADS >> logw) << blog;

@@ -8,6 +8,7 @@ struct GeomSpec {
     uint32_t c_m, q_m;  // Montgomery form
     uint64_t stride;
     uint32_t count;
+    uint32_t pair;      // 1: write Tw2 entries (value, value * p^-1 mod 2^32)
 };
 
 struct FieldSetup {
@@ -41,9 +42,9 @@ inline void ntt_table_specs(const FieldSetup &fs, int inverse, GeomSpec specs[3]
     const Fp &F = fs.F;
     const uint32_t w_m = (uint32_t)(((uint64_t)fs.wmax[inverse ? 1 : 0] << 32) % F.p);
     const uint32_t h = ntt_table_h(fs.K);
-    specs[0] = GeomSpec{F.r1, w_m, 1ull << (fs.K - SMI_TW_LOG), 1u << SMI_TW_LOG};
-    specs[1] = GeomSpec{F.r1, w_m, 1, 1u << h};
-    specs[2] = GeomSpec{F.r1, w_m, 1ull << h, 1u << (fs.K - h)};
+    specs[0] = GeomSpec{F.r1, w_m, 1ull << (fs.K - SMI_TW_LOG), 1u << SMI_TW_LOG, 1};
+    specs[1] = GeomSpec{F.r1, w_m, 1, 1u << h, 0};
+    specs[2] = GeomSpec{F.r1, w_m, 1ull << h, 1u << (fs.K - h), 0};
 }
 
 // c * q^i for i < 2^L, two-level: lo (2^h entries, ratio q), hi (2^(L-h) entries, c * q^(i<<h))
@@ -51,6 +52,14 @@ inline uint32_t scale_table_h(uint32_t L) { return (L + 1) / 2; }
 inline void scale_table_specs(const Fp &F, uint32_t c_plain, uint32_t q_plain, uint32_t L, GeomSpec specs[2]) {
     const uint32_t c_m = (uint32_t)(((uint64_t)c_plain << 32) % F.p), q_m = (uint32_t)(((uint64_t)q_plain << 32) % F.p);
     const uint32_t h = scale_table_h(L);
-    specs[0] = GeomSpec{F.r1, q_m, 1, 1u << h};
-    specs[1] = GeomSpec{c_m, q_m, 1ull << h, 1u << (L - h)};
+    specs[0] = GeomSpec{F.r1, q_m, 1, 1u << h, 0};
+    specs[1] = GeomSpec{c_m, q_m, 1ull << h, 1u << (L - h), 0};
+}
+
+// Inter-pass twiddle table of one pass: entry [k*B + b] = w_m^(k*b), m = 2^mlog = R*B (Tw2 pairs).
+SMI_HD Tw2 pass_table_entry(uint32_t idx, uint32_t mlog, uint32_t logr, const NttTables &T, const Fp &F) {
+    const uint32_t blog = mlog - logr, k = idx >> blog, b = idx & ((1u << blog) - 1u);
+    const uint32_t e = (k * b) << (T.K - mlog);
+    const uint32_t v = e ? two_level(T.lo, T.hi, T.h, e, F) : F.r1;
+    return Tw2{v, v * F.pinv};
 }
