@@ -22,19 +22,19 @@ std::vector<uint32_t> fill(const GeomSpec &s, const Fp &F) {
     return t;
 }
 
-template <int LOGR, bool LAST> void emu_pass(const PassArgs &a, uint32_t batch) {
-    typedef NttPass<LOGR, LAST> NP;
+template <int LOGR, int LOGW, bool LAST> void emu_pass(const PassArgs &a, uint32_t batch) {
+    typedef NttPass<LOGR, LOGW, LAST> NP;
     std::vector<uint32_t> tile(NP::R * NP::WP);
     std::vector<Tw2> tw(NP::R);
     for (uint32_t b = 0; b < batch; b++)
         for (uint32_t blk = 0; blk < a.n_tiles; blk++) {
             typename NP::TileId t = NP::tile_id(a, blk);
-            for (uint32_t tid = 0; tid < SMI_NTT_THREADS; tid++) NP::load_tw(a, tw.data(), tid);
-            for (uint32_t tid = 0; tid < SMI_NTT_THREADS; tid++) NP::load(a, t, b, tile.data(), tid);
-            for (uint32_t tid = 0; tid < SMI_NTT_THREADS; tid++) NP::template step_i<0>(a, tile.data(), tw.data(), tid);
-            for (uint32_t tid = 0; tid < SMI_NTT_THREADS; tid++) NP::template step_i<1>(a, tile.data(), tw.data(), tid);
-            for (uint32_t tid = 0; tid < SMI_NTT_THREADS; tid++) NP::template step_i<2>(a, tile.data(), tw.data(), tid);
-            for (uint32_t tid = 0; tid < SMI_NTT_THREADS; tid++) NP::store(a, t, b, tile.data(), tid);
+            for (uint32_t tid = 0; tid < (uint32_t)NP::NT; tid++) NP::load_tw(a, tw.data(), tid);
+            for (uint32_t tid = 0; tid < (uint32_t)NP::NT; tid++) NP::load(a, t, b, tile.data(), tid);
+            for (uint32_t tid = 0; tid < (uint32_t)NP::NT; tid++) NP::template step_i<0>(a, tile.data(), tw.data(), tid);
+            for (uint32_t tid = 0; tid < (uint32_t)NP::NT; tid++) NP::template step_i<1>(a, tile.data(), tw.data(), tid);
+            for (uint32_t tid = 0; tid < (uint32_t)NP::NT; tid++) NP::template step_i<2>(a, tile.data(), tw.data(), tid);
+            for (uint32_t tid = 0; tid < (uint32_t)NP::NT; tid++) NP::store(a, t, b, tile.data(), tid);
         }
 }
 
@@ -56,14 +56,15 @@ struct EmuLauncher {
             for (uint32_t tid = 0; tid < SMI_NTT_THREADS; tid++) NttSmall::store(a, b, buf.data(), tid);
         }
     }
-    void pass(int logr, bool last, const PassArgs &a, uint32_t batch) {
-#define CASE(LR)                                                   \
-    case LR:                                                       \
-        if (last) emu_pass<LR, true>(a, batch);                    \
-        else emu_pass<LR, false>(a, batch);                        \
-        break;
-        switch (logr) { CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) }
-#undef CASE
+    void pass(int logr, int logw, bool last, const PassArgs &a, uint32_t batch) {
+#define X(LR, LW)                                           \
+    if (logr == LR && logw == LW) {                         \
+        if (last) emu_pass<LR, LW, true>(a, batch);         \
+        else emu_pass<LR, LW, false>(a, batch);             \
+        return;                                             \
+    }
+        SMI_NTT_SHAPES(X)
+#undef X
     }
 };
 

@@ -8,9 +8,9 @@
 #include "ntt_driver.h"
 
 // ------------------------------------------------------------------------- kernels
-template <int LOGR, bool LAST>
-__global__ __launch_bounds__(SMI_NTT_THREADS) void ntt_pass_kernel(const PassArgs a) {
-    typedef NttPass<LOGR, LAST> NP;
+template <int LOGR, int LOGW, bool LAST>
+__global__ __launch_bounds__(1 << (LOGR + LOGW - 4)) void ntt_pass_kernel(const PassArgs a) {
+    typedef NttPass<LOGR, LOGW, LAST> NP;
     __shared__ uint32_t tile[NP::R * NP::WP];
     __shared__ Tw2 tw[NP::R];
     const uint32_t tid = threadIdx.x, batch = blockIdx.y;
@@ -109,26 +109,23 @@ struct HipLauncher {
         ntt_small_kernel<<<batch, SMI_NTT_THREADS, 0, ctx->stream>>>(a);
         note();
     }
-    void pass(int logr, bool last, const PassArgs &a, uint32_t batch) {
+    void pass(int logr, int logw, bool last, const PassArgs &a, uint32_t batch) {
         const dim3 grid(a.n_tiles, batch);
         // algorithmic bytes of one pass: every point read once and written once (4 B each);
         // the first pass of a zero-padded transform reads only its n_in real inputs
         const double n = (double)(1ull << a.L);
         const double bytes = ((a.flags & NTT_FIRST) ? 4.0 * a.n_in : 4.0 * n) * batch + 4.0 * n * batch;
-        static const char *names[5][2] = {{"ntt_pass_kernel<6,false>", "ntt_pass_kernel<6,true>"},
-                                          {"ntt_pass_kernel<7,false>", "ntt_pass_kernel<7,true>"},
-                                          {"ntt_pass_kernel<8,false>", "ntt_pass_kernel<8,true>"},
-                                          {"ntt_pass_kernel<9,false>", "ntt_pass_kernel<9,true>"},
-                                          {"ntt_pass_kernel<10,false>", "ntt_pass_kernel<10,true>"}};
-        ProfScope ps(ctx, names[logr - 6][last ? 1 : 0], bytes);
-#define CASE(LR)                                                                                  \
-    case LR:                                                                                      \
-        if (last) ntt_pass_kernel<LR, true><<<grid, SMI_NTT_THREADS, 0, ctx->stream>>>(a);        \
-        else ntt_pass_kernel<LR, false><<<grid, SMI_NTT_THREADS, 0, ctx->stream>>>(a);            \
-        break;
-        switch (logr) { CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) }
-#undef CASE
-        note();
+#define X(LR, LW)                                                                                              \
+    if (logr == LR && logw == LW) {                                                                            \
+        ProfScope ps(ctx, last ? "ntt_pass_kernel<" #LR "," #LW ",last>" : "ntt_pass_kernel<" #LR "," #LW ">", bytes); \
+        if (last) ntt_pass_kernel<LR, LW, true><<<grid, 1 << (LR + LW - 4), 0, ctx->stream>>>(a);              \
+        else ntt_pass_kernel<LR, LW, false><<<grid, 1 << (LR + LW - 4), 0, ctx->stream>>>(a);                  \
+        note();                                                                                                \
+        return;                                                                                                \
+    }
+        SMI_NTT_SHAPES(X)
+#undef X
+        if (err == hipSuccess) err = hipErrorInvalidValue;
     }
     int inverse = 0;
     const Tw2 *pass_table(uint32_t mlog, uint32_t logr) {

@@ -21,9 +21,9 @@
 #pragma once
 #include "field.h"
 
-#define SMI_TILE_LOG 12
+#define SMI_TILE_LOG 12          // smallest tile (and the size limit of the single-workgroup kernel)
 #define SMI_TILE (1u << SMI_TILE_LOG)
-#define SMI_NTT_THREADS 256
+#define SMI_NTT_THREADS 256      // threads of the small kernel; pass kernels use tile/16 threads
 #define SMI_TW_LOG 10   // in-tile twiddle table: w_1024^j
 
 // A table twiddle with its Montgomery companion q = w * p^-1 mod 2^32 (see mont_mul_c).
@@ -115,8 +115,9 @@ template <int S> SMI_HD void dft_regs(uint32_t (&x)[1 << S], const Tw2 *cw, int 
     }
 }
 
-template <int LOGR, bool LAST> struct NttPass {
-    enum { LOGW = SMI_TILE_LOG - LOGR, R = 1 << LOGR, W = 1 << LOGW, WP = W + 1, V = SMI_TILE / SMI_NTT_THREADS };
+// A tile is R = 2^LOGR points x W = 2^LOGW lines, 16 points per thread (NT = R*W/16 threads).
+template <int LOGR, int LOGW, bool LAST> struct NttPass {
+    enum { TILE_LOG = LOGR + LOGW, TILE = 1 << TILE_LOG, NT = TILE / 16, R = 1 << LOGR, W = 1 << LOGW, WP = W + 1, V = 16 };
     typedef Steps<LOGR> St;
 
     struct TileId {  // wave-uniform description of the tile this workgroup owns
@@ -157,8 +158,8 @@ template <int LOGR, bool LAST> struct NttPass {
 
     static SMI_HD void load_tw(const PassArgs &a, Tw2 *tw, uint32_t tid) {
 #pragma unroll
-        for (int i = 0; i < (R + SMI_NTT_THREADS - 1) / SMI_NTT_THREADS; i++) {
-            uint32_t j = tid + i * SMI_NTT_THREADS;
+        for (int i = 0; i < (R + NT - 1) / NT; i++) {
+            uint32_t j = tid + i * NT;
             if (j < (uint32_t)R) tw[j] = a.T.tw10[j << (SMI_TW_LOG - LOGR)];
         }
     }
@@ -178,8 +179,8 @@ template <int LOGR, bool LAST> struct NttPass {
             if (a.flags & NTT_PRE_SCALE) sc = o0 < lim ? two_level(a.S.lo, a.S.hi, a.S.h, t.b0 + o0, a.F) : 0u;
 #pragma unroll
             for (int i = 0; i < V; i++) {
-                const uint32_t j = j0 + i * (SMI_NTT_THREADS >> LOGW);
-                const uint32_t o = o0 + ((uint32_t)(i * (SMI_NTT_THREADS >> LOGW)) << blog);
+                const uint32_t j = j0 + i * (NT >> LOGW);
+                const uint32_t o = o0 + ((uint32_t)(i * (NT >> LOGW)) << blog);
                 uint32_t v = o < lim ? in[o] : 0u;
                 if (a.flags & NTT_PRE_SCALE) {
                     v = mont_mul(v, sc, a.F);
@@ -191,7 +192,7 @@ template <int LOGR, bool LAST> struct NttPass {
             const uint32_t arest_log = a.Sp - a.d0_log;
 #pragma unroll
             for (int i = 0; i < V; i++) {
-                const uint32_t idx = tid + i * SMI_NTT_THREADS;
+                const uint32_t idx = tid + i * NT;
                 const uint32_t j = idx & (R - 1), l = idx >> LOGR;
                 tile[j * WP + l] = in[(l << (arest_log + LOGR)) + j];
             }
@@ -200,10 +201,10 @@ template <int LOGR, bool LAST> struct NttPass {
 
     // One radix-2^S step on sub-blocks of 2^MLOG points (MLOG = log2 M of this step).
     template <int S, int MLOG> static SMI_HD void step(const PassArgs &a, uint32_t *tile, const Tw2 *tw, uint32_t tid) {
-        enum { r = 1 << S, SUB = MLOG - S, NB = (SMI_TILE / r) / SMI_NTT_THREADS };
+        enum { r = 1 << S, SUB = MLOG - S, NB = (TILE / r) / NT };
 #pragma unroll
         for (int bi = 0; bi < NB; bi++) {
-            const uint32_t u = tid + bi * SMI_NTT_THREADS;
+            const uint32_t u = tid + bi * NT;
             const uint32_t w = u & (W - 1), ub = u >> LOGW;
             const uint32_t blk = ub >> SUB, pos = ub & ((1u << SUB) - 1u);
             const uint32_t base = (blk << MLOG) + pos;
@@ -267,7 +268,7 @@ template <int LOGR, bool LAST> struct NttPass {
                 const Tw2 *tab = a.ptab + t.b0;
 #pragma unroll
                 for (int i = 0; i < V; i++) {
-                    const uint32_t loc = loc0 + i * (SMI_NTT_THREADS >> LOGW);
+                    const uint32_t loc = loc0 + i * (NT >> LOGW);
                     const uint32_t o = o0 + ((uint32_t)i << blog);
                     const Tw2 c = tab[o];
                     out[o] = mont_mul_c(tile[loc * WP + w], c.w, c.q, a.F);
@@ -281,7 +282,7 @@ template <int LOGR, bool LAST> struct NttPass {
                 uint32_t cur = two_level(a.T.lo, a.T.hi, a.T.h, (b * (krest << 4)) << sh, a.F);
 #pragma unroll
                 for (int i = 0; i < V; i++) {
-                    const uint32_t loc = loc0 + i * (SMI_NTT_THREADS >> LOGW);
+                    const uint32_t loc = loc0 + i * (NT >> LOGW);
                     const uint32_t v = mont_mul(tile[loc * WP + w], cur, a.F);
                     cur = mont_mul_c(cur, g, gq, a.F);
                     out[o0 + ((uint32_t)i << blog)] = v;
@@ -294,7 +295,7 @@ template <int LOGR, bool LAST> struct NttPass {
             const uint32_t rq = a.post_ratio_m * a.F.pinv;
 #pragma unroll
             for (int i = 0; i < V; i++) {
-                const uint32_t loc = loc0 + i * (SMI_NTT_THREADS >> LOGW);
+                const uint32_t loc = loc0 + i * (NT >> LOGW);
                 uint32_t v = tile[loc * WP + w];
                 if (a.flags & NTT_POST_SCALE) {
                     v = mont_mul(v, sc, a.F);

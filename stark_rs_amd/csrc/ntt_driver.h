@@ -22,7 +22,7 @@ struct NttRequest {
 
 // Launcher concept:
 //   void small(const SmallArgs&, uint32_t batch);
-//   void pass(int logr, bool last, const PassArgs&, uint32_t batch);
+//   void pass(int logr, int logw, bool last, const PassArgs&, uint32_t batch);
 //   const Tw2 *pass_table(uint32_t mlog, uint32_t logr);   // w_m^(k*b) table (cached), or nullptr
 template <class Launcher> inline void ntt_run(Launcher &ln, const NttRequest &rq) {
     const NttPlan pl = ntt_make_plan(rq.L);
@@ -51,16 +51,16 @@ template <class Launcher> inline void ntt_run(Launcher &ln, const NttRequest &rq
         a.d0_log = (uint32_t)pl.logr[0];
         a.n_mid = (uint32_t)(pl.np - 2);
         for (int d = 0; d < pl.np - 2; d++) a.mid_log[d] = (uint32_t)pl.logr[1 + d];
-        a.n_tiles = (uint32_t)(n >> SMI_TILE_LOG);
+        a.n_tiles = (uint32_t)(n >> (pl.logr[p] + pl.logw[p]));
         a.ptab = (!first && !last) ? ln.pass_table(rq.L - consumed, (uint32_t)pl.logr[p]) : nullptr;
         {   // steps of the running-product scales (see NttPass::load / store)
-            const uint32_t logw = SMI_TILE_LOG - (uint32_t)pl.logr[p], blog = rq.L - consumed - (uint32_t)pl.logr[p];
-            const uint64_t pre_step = (uint64_t)(SMI_NTT_THREADS >> logw) << blog;
+            const uint32_t logw = (uint32_t)pl.logw[p], blog = rq.L - consumed - (uint32_t)pl.logr[p];
+            const uint64_t pre_step = (uint64_t)((1u << (pl.logr[p] + pl.logw[p] - 4)) >> logw) << blog;
             const uint32_t pr = host_powmod(rq.q_plain, pre_step, rq.F.p), po = host_powmod(rq.q_plain, 1ull << consumed, rq.F.p);
             a.pre_ratio_m = (uint32_t)(((uint64_t)pr << 32) % rq.F.p);
             a.post_ratio_m = (uint32_t)(((uint64_t)po << 32) % rq.F.p);
         }
-        ln.pass(pl.logr[p], last, a, rq.batch);
+        ln.pass(pl.logr[p], pl.logw[p], last, a, rq.batch);
         consumed += (uint32_t)pl.logr[p];
     }
 }

@@ -10,33 +10,46 @@
 
 struct NttPlan {
     int np;        // 0 = single small-kernel launch
-    int logr[4];
+    int logr[4];   // digit of pass p
+    int logw[4];   // lines per tile of pass p (tile = 2^(logr+logw) points, 12..14)
 };
 
-// n = 2^L split into np digits of 6..10 bits, larger first.  Constraints the kernels rely on:
-//   strided pass p: B_p >= W_p  <=>  L - S_{p+1} >= 12 - l_p
-//   last pass:      R_0 >= W_last <=> l_0 >= 12 - l_last
+// Kernels exist for these (logr, logw) pairs (ntt.hip instantiates exactly this list).
+#define SMI_NTT_SHAPES(X) \
+    X(6, 6) X(7, 5) X(8, 4) X(9, 3) X(10, 2) /* 4096-point tiles  */ \
+    X(7, 6) X(8, 5) X(9, 4) X(10, 3)         /* 8192-point tiles  */ \
+    X(8, 6) X(9, 5) X(10, 4)                 /* 16384-point tiles */
+inline bool ntt_shape_ok(int lr, int lw) {
+#define X(a, b) if (lr == a && lw == b) return true;
+    SMI_NTT_SHAPES(X)
+#undef X
+    return false;
+}
+
+// n = 2^L split into np digits.  Constraints the kernels rely on:
+//   strided pass p: B_p >= W_p   <=>  L - S_{p+1} >= logw_p
+//   last pass:      R_0 >= W_last <=> logr_0 >= logw_last
 inline bool ntt_plan_valid(uint32_t L, const NttPlan &pl) {
     if (pl.np < 2 || pl.np > 4) return false;
     int sum = 0;
     for (int i = 0; i < pl.np; i++) {
-        if (pl.logr[i] < 6 || pl.logr[i] > 10) return false;
+        if (!ntt_shape_ok(pl.logr[i], pl.logw[i])) return false;
         sum += pl.logr[i];
     }
     if (sum != (int)L) return false;
     int consumed = 0;
     for (int i = 0; i + 1 < pl.np; i++) {
         consumed += pl.logr[i];
-        if ((int)L - consumed < SMI_TILE_LOG - pl.logr[i]) return false;
+        if ((int)L - consumed < pl.logw[i]) return false;
     }
-    return pl.logr[0] >= SMI_TILE_LOG - pl.logr[pl.np - 1];
+    return pl.logr[0] >= pl.logw[pl.np - 1];
 }
 
 inline NttPlan ntt_make_plan(uint32_t L) {
     NttPlan pl;
     memset(&pl, 0, sizeof pl);
     if (L <= SMI_TILE_LOG) return pl;  // np = 0
-    // optional override for tuning: SMI_NTT_PLAN_<L>="10,10"
+    // optional override for tuning: SMI_NTT_PLAN_<L>="10.2,10.2" (logr.logw per pass)
     char name[32];
     snprintf(name, sizeof name, "SMI_NTT_PLAN_%u", L);
     if (const char *env = getenv(name)) {
@@ -44,7 +57,10 @@ inline NttPlan ntt_make_plan(uint32_t L) {
         memset(&o, 0, sizeof o);
         const char *s = env;
         while (*s && o.np < 4) {
-            o.logr[o.np++] = (int)strtol(s, (char **)&s, 10);
+            o.logr[o.np] = (int)strtol(s, (char **)&s, 10);
+            if (*s == '.') s++;
+            o.logw[o.np] = (int)strtol(s, (char **)&s, 10);
+            o.np++;
             if (*s == ',') s++;
         }
         if (ntt_plan_valid(L, o)) return o;
@@ -55,6 +71,20 @@ inline NttPlan ntt_make_plan(uint32_t L) {
         int left = pl.np - i;
         pl.logr[i] = (rem + left - 1) / left;  // ceil: larger digits first
         rem -= pl.logr[i];
+    }
+    // widest lines that fit: strided passes want >= 128-byte runs (W >= 32), see DESIGN.md
+    int consumed = 0;
+    for (int i = 0; i < pl.np; i++) {
+        consumed += pl.logr[i];
+        const bool last = i == pl.np - 1;
+        const int limit = last ? pl.logr[0] : (int)L - consumed;
+        int best = -1;
+        for (int lw = 2; lw <= 6; lw++)
+            if (ntt_shape_ok(pl.logr[i], lw) && lw <= limit && pl.logr[i] + lw <= (last ? 13 : 14) && lw <= (last ? 4 : 5)) best = lw;
+        if (best < 0)
+            for (int lw = 6; lw >= 2; lw--)
+                if (ntt_shape_ok(pl.logr[i], lw) && lw <= limit) best = lw;
+        pl.logw[i] = best;
     }
     return pl;
 }

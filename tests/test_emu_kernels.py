@@ -83,3 +83,21 @@ def test_emulated_hash_core(emu, oracle):
         ob = (C.c_uint8 * 32)()
         emu.emu_hash_bytes(m, C.c_size_t(n), ob)
         assert bytes(ob) == o.hash_from_bytes(m)
+
+
+@pytest.mark.parametrize("L,plan", [
+    (18, "9.3,9.3"), (18, "9.5,9.4"), (18, "10.4,8.4"), (18, "6.6,6.6,6.6"), (19, "7.6,6.6,6.6"), (20, "10.2,10.2"),
+    (20, "10.4,10.3"), (20, "7.5,7.5,6.6"), (20, "8.6,6.6,6.6"), (21, "8.5,7.6,6.6"), (21, "9.4,6.6,6.6"),
+])
+def test_emulated_ntt_explicit_tile_shapes(emu, oracle, L, plan):
+    """Every instantiated (logr, logw) tile shape, selected through the tuning override."""
+    o = oracle
+    os.environ[f"SMI_NTT_PLAN_{L}"] = plan
+    try:
+        n = 1 << L
+        w = o.ff_prim_nth_root(n)
+        vals = o.splitmix64(L, n) % np.uint64(P)
+        assert np.array_equal(_ntt(emu, P, G, vals, L, n, 1, 3), o.fast_intt(vals, w, 3))
+        assert np.array_equal(_ntt(emu, P, G, vals[: n // 8], L, n // 8, 0, 3), o.fast_coset_ntt(vals[: n // 8], n, w, 3))
+    finally:
+        del os.environ[f"SMI_NTT_PLAN_{L}"]
