@@ -164,6 +164,10 @@ int dev_ntt(smi_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint32_t log_n,
     // d_in == d_out is always safe: every pass (and the small kernel) has read all of its
     // input into LDS / the scratch buffer before anything is written to d_out.
 
+    if (n_in == 0) {  // Polynomial::eval_domain of the empty polynomial: all zeros (src/univariate/eval.rs:6-14)
+        for (uint32_t c = 0; c < batch; c++) HIP_TRY(ctx, hipMemsetAsync(d_out + (size_t)c * out_stride, 0, n * 4, ctx->stream));
+        return SMI_OK;
+    }
     NttRequest rq;
     memset(&rq, 0, sizeof rq);
     rq.in = d_in; rq.out = d_out; rq.L = log_n; rq.n_in = (uint32_t)n_in; rq.batch = batch;

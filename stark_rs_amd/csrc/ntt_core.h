@@ -173,28 +173,45 @@ template <int LOGR, int LOGW, bool LAST> struct NttPass {
             // g = g0 + i*(T<<blog) advances by the constant pre_ratio = q^(T<<blog).
             const uint32_t w = tid & (W - 1), j0 = tid >> LOGW;
             const uint32_t o0 = (j0 << blog) + w;
-            // in_base == b0 in the first pass (one sub-problem), so g = b0 + offset is the natural index
-            const uint32_t lim = (a.flags & NTT_FIRST) ? (a.n_in > t.b0 ? a.n_in - t.b0 : 0u) : 0xFFFFFFFFu;
-            uint32_t sc = 0;
-            if (a.flags & NTT_PRE_SCALE) sc = o0 < lim ? two_level(a.S.lo, a.S.hi, a.S.h, t.b0 + o0, a.F) : 0u;
+            uint32_t v[V];
+            if (a.flags & NTT_FIRST) {
+                // zero padding: in_base == b0 in the first pass, so b0 + o is the natural index.
+                // Branch-free (clamped address + select) so the 16 loads issue back to back.
+                const uint32_t *col = a.in + (uint64_t)batch * a.in_stride;
 #pragma unroll
-            for (int i = 0; i < V; i++) {
-                const uint32_t j = j0 + i * (NT >> LOGW);
-                const uint32_t o = o0 + ((uint32_t)(i * (NT >> LOGW)) << blog);
-                uint32_t v = o < lim ? in[o] : 0u;
-                if (a.flags & NTT_PRE_SCALE) {
-                    v = mont_mul(v, sc, a.F);
-                    sc = mont_mul(sc, a.pre_ratio_m, a.F);
+                for (int i = 0; i < V; i++) {
+                    const uint32_t g = t.b0 + o0 + ((uint32_t)(i * (NT >> LOGW)) << blog);
+                    const uint32_t x = col[g < a.n_in ? g : 0u];
+                    v[i] = g < a.n_in ? x : 0u;
                 }
-                tile[j * WP + w] = v;
+                if (a.flags & NTT_PRE_SCALE) {
+                    uint32_t sc = two_level(a.S.lo, a.S.hi, a.S.h, t.b0 + o0, a.F);
+                    const uint32_t rq = a.pre_ratio_m * a.F.pinv;
+#pragma unroll
+                    for (int i = 0; i < V; i++) {
+                        v[i] = mont_mul(v[i], sc, a.F);
+                        sc = mont_mul_c(sc, a.pre_ratio_m, rq, a.F);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < V; i++) v[i] = in[o0 + ((uint32_t)(i * (NT >> LOGW)) << blog)];
             }
+#pragma unroll
+            for (int i = 0; i < V; i++) tile[(j0 + i * (NT >> LOGW)) * WP + w] = v[i];
         } else {
             const uint32_t arest_log = a.Sp - a.d0_log;
+            uint32_t v[V];
 #pragma unroll
             for (int i = 0; i < V; i++) {
                 const uint32_t idx = tid + i * NT;
                 const uint32_t j = idx & (R - 1), l = idx >> LOGR;
-                tile[j * WP + l] = in[(l << (arest_log + LOGR)) + j];
+                v[i] = in[(l << (arest_log + LOGR)) + j];
+            }
+#pragma unroll
+            for (int i = 0; i < V; i++) {
+                const uint32_t idx = tid + i * NT;
+                tile[(idx & (R - 1)) * WP + (idx >> LOGR)] = v[i];
             }
         }
     }
