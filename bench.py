@@ -170,7 +170,8 @@ def main():
     if not args.no_extras:
         # ---- end-to-end prove of the same trace (build-defined composition)
         try:
-            eng.dev_stark_prove(trace.data_ptr(), N_COLS, LOG_ROWS, LOG_BLOWUP, N_TESTS)   # warm-up (sizes the arena)
+            for _ in range(2):   # warm-up: the first call sizes the device arena, the second allocates it
+                eng.dev_stark_prove(trace.data_ptr(), N_COLS, LOG_ROWS, LOG_BLOWUP, N_TESTS)
             barrier()
             torch.cuda.synchronize()
             tp = time.perf_counter()

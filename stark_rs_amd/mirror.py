@@ -1,0 +1,503 @@
+"""Host-side mirror of the reference's types for the hot path -- same names, argument meaning
+and error behaviour as 0xSooki/stark-rs, with the heavy methods routed through the C ABI
+(include/stark_mi.h) onto the GPU.  The Rust binding a maintainer would add is shown in
+INTEGRATION.md; this mirror exists so the parity tests read like the reference's own tests
+(tests/test_gpu_mirror.py transliterates them).
+
+Scalar field operations (FiniteField::add/sub/mul/...) are plain host integer arithmetic, as in
+the reference (src/ff.rs:138-233) -- they are the glue between kernel calls, not the hot path.
+Anything that touches a whole codeword, polynomial or tree goes to the device:
+
+    Polynomial.interpolate_domain / eval_domain / scale   -> smi_intt / smi_coset_ntt / smi_poly_scale
+    Hash.from_field_elements / combine / from_bytes       -> smi_hash_* (device kernels, even for one digest)
+    MerkleTree.new / commit / open                        -> smi_merkle_*
+    FiatShamir.challenge                                   -> smi_hash_bytes
+    Fri.fold_codeword / commit / prove                     -> smi_fri_fold / smi_fri_commit / smi_fri_prove
+
+Domains that are not geometric (offset * omega^k) have no fast path: the mirror raises
+StarkMiError("domain is not offset*omega^k") -- the Rust shim falls back to the original CPU
+code there; this package has no CPU compute path by design.
+"""
+import numpy as np
+
+from ._lib import StarkMiError
+from .engine import P_REF, default_engine
+
+PANIC = StarkMiError  # a reference panic surfaces as this exception with the identical message
+
+
+class FiniteField:
+    """src/ff.rs:9-12,108-233"""
+
+    def __init__(self, p):
+        self.p = p
+
+    def __eq__(self, o):
+        return isinstance(o, FiniteField) and self.p == o.p
+
+    def __hash__(self):
+        return hash(self.p)
+
+    def modulus(self):
+        return self.p
+
+    def new_element(self, value):
+        return FieldElement(value, self)      # unreduced, like src/ff.rs:113-118
+
+    def zero(self):
+        return FieldElement(0, self)
+
+    def one(self):
+        return FieldElement(1, self)
+
+    def add(self, l, r):
+        return FieldElement((l.value + r.value) % self.p, self)
+
+    def sub(self, l, r):
+        return FieldElement((self.p + l.value - r.value) % self.p, self)
+
+    def mul(self, l, r):
+        return FieldElement((l.value * r.value) % self.p, self)
+
+    def neg(self, x):
+        return FieldElement((self.p - x.value) % self.p, self)
+
+    def inv(self, x):
+        if x.value % self.p == 0:
+            raise StarkMiError(-1, "no inverse")                  # src/ff.rs:171
+        return FieldElement(pow(x.value, -1, self.p), self)
+
+    def div(self, l, r):
+        if r.value == 0:
+            raise StarkMiError(-2, "no division by zero")         # src/ff.rs:182
+        return self.mul(l, self.inv(r))
+
+    def exp(self, base, e):
+        return FieldElement(pow(base.value, e, self.p), self)
+
+    def g(self):
+        if self.p != P_REF:
+            raise StarkMiError(-16, "assertion failed: self.p == 998244353")   # src/ff.rs:192
+        return FieldElement(3, self)
+
+    def prim_nth_root(self, n):
+        if self.p != P_REF:
+            raise StarkMiError(-16, "assertion failed: self.p == 998244353")   # src/ff.rs:216
+        if n == 0 or n & (n - 1):
+            raise StarkMiError(-3, "n must be a power of two")                 # src/ff.rs:217
+        if n > (1 << 23):
+            raise StarkMiError(-4, "n > 2^23 not supported by this modulus")   # src/ff.rs:218
+        return self.exp(self.g(), (self.p - 1) // n)
+
+    def sample(self, salt: bytes):
+        acc = 0
+        for b in salt:                                             # src/ff.rs:225-232
+            acc = (acc << 8) % self.p
+            acc = (acc ^ b) % self.p
+        return FieldElement(acc, self)
+
+    def engine(self):
+        """The GPU context for this modulus (one per process)."""
+        if self.p == P_REF:
+            return default_engine()
+        from .engine import G2, P2
+        if self.p == P2:
+            return default_engine(P2, G2)
+        raise StarkMiError(-52, f"unsupported modulus for this size: no generator registered for p={self.p}")
+
+
+class FieldElement:
+    """src/ff.rs:24-28 plus the operator impls (:30-106, :235-281)"""
+    __slots__ = ("value", "field")
+
+    def __init__(self, value, field):
+        self.value, self.field = value, field
+
+    def __eq__(self, o):
+        return isinstance(o, FieldElement) and self.value == o.value and self.field == o.field
+
+    def __hash__(self):
+        return hash((self.value, self.field.p))
+
+    def __lt__(self, o):
+        return self.value < o.value
+
+    def __add__(self, o):
+        return self.field.add(self, o)
+
+    def __sub__(self, o):
+        return self.field.sub(self, o)
+
+    def __mul__(self, o):
+        return self.field.mul(self, o)
+
+    def __truediv__(self, o):
+        return self.field.div(self, o)
+
+    def __neg__(self):
+        return self.field.neg(self)
+
+    def __xor__(self, e):
+        return self.field.exp(self, e)
+
+    def pow(self, e):
+        return self.field.exp(self, e)
+
+    def __repr__(self):
+        return f"FieldElement({self.value})"
+
+
+def _vals(elems):
+    return np.fromiter((e.value for e in elems), dtype=np.uint64, count=len(elems))
+
+
+class Polynomial:
+    """src/univariate/mod.rs:8-153 (+ interpolate.rs, eval.rs); ascending coefficients."""
+
+    def __init__(self, coeffs, field):
+        self.coeffs, self.field = list(coeffs), field
+
+    new = classmethod(lambda cls, coeffs, field: cls(coeffs, field))
+
+    @staticmethod
+    def zero_poly(field):
+        return Polynomial([], field)
+
+    @staticmethod
+    def constant_poly(field, value):
+        return Polynomial([field.new_element(value)], field)
+
+    @staticmethod
+    def linear_poly(field, a, b):
+        return Polynomial([field.new_element(a), field.new_element(b)], field)
+
+    def deg(self):
+        d = -1
+        for i, c in enumerate(self.coeffs):
+            if c.value != 0:
+                d = i
+        return d
+
+    def is_zero(self):
+        return self.deg() == -1
+
+    def __eq__(self, o):                                            # mod.rs:13-39: trailing zeros ignored
+        if self.deg() != o.deg():
+            return False
+        return all(self.coeffs[i] == o.coeffs[i] for i in range(self.deg() + 1))
+
+    def scale(self, factor):
+        """f(cX) -- mod.rs:99-113, on the device."""
+        if not self.coeffs:
+            return Polynomial([], self.field)
+        out = self.field.engine().poly_scale(_vals(self.coeffs), factor.value % self.field.p)
+        return Polynomial([FieldElement(int(v), self.field) for v in out], self.field)
+
+    @staticmethod
+    def interpolate_domain(domain, values):
+        """interpolate.rs:6-44 for a geometric domain offset*omega_n^k (the fast-path contract)."""
+        if len(domain) != len(values):
+            raise StarkMiError(-14, "assertion failed: domain.len() == values.len()")
+        if len(domain) == 0:
+            raise StarkMiError(-15, "assertion failed: domain.len() > 0")
+        field = domain[0].field
+        eng = field.engine()
+        d = _vals(domain)
+        if len(set(int(x) for x in d)) != len(d):
+            raise StarkMiError(-1, "no inverse")                    # duplicate points: ff.rs:171 via interpolate.rs:34
+        ok, offset = eng.domain_is_geometric(d)
+        if not ok:
+            raise StarkMiError(-53, "domain is not offset*omega^k")
+        v = _vals(values)
+        out = eng.intt(v, offset)
+        if len(v) > 1 and not v.any():
+            return Polynomial([], field)                            # H8: all-zero values give the empty polynomial
+        return Polynomial([FieldElement(int(c), field) for c in out], field)
+
+    def eval(self, x):
+        """eval.rs:6-14 -- one point: host Horner-equivalent (not the hot path)."""
+        p = self.field.p
+        acc = 0
+        for c in reversed(self.coeffs):
+            acc = (acc * x.value + c.value) % p
+        return FieldElement(acc, self.field)
+
+    def eval_domain(self, domain):
+        """eval.rs:16-21 on a geometric domain, in domain order, on the device."""
+        if not domain:
+            return []
+        field = domain[0].field
+        eng = field.engine()
+        d = _vals(domain)
+        ok, offset = eng.domain_is_geometric(d)
+        n_c = self.deg() + 1
+        if not ok or n_c > len(d):
+            raise StarkMiError(-53, "domain is not offset*omega^k")
+        out = eng.coset_ntt(_vals(self.coeffs[:n_c]), len(d).bit_length() - 1, offset)
+        return [FieldElement(int(v), field) for v in out]
+
+
+class Hash:
+    """src/hash.rs:1-46; digests are computed by the device kernels."""
+    __slots__ = ("bytes",)
+
+    def __init__(self, b):
+        self.bytes = bytes(b)
+
+    @property
+    def _0(self):
+        return self.bytes
+
+    def __eq__(self, o):
+        return isinstance(o, Hash) and self.bytes == o.bytes
+
+    def __hash__(self):
+        return hash(self.bytes)
+
+    @staticmethod
+    def from_bytes(data: bytes):
+        return Hash(default_engine().hash_bytes(bytes(data)))
+
+    @staticmethod
+    def from_field_elements(elements):
+        b = b"".join(int(e).to_bytes(8, "little") for e in elements)    # hash.rs:32-35
+        return Hash.from_bytes(b)
+
+    @staticmethod
+    def from_u64(value):
+        return Hash.from_bytes(int(value).to_bytes(8, "little"))
+
+    @staticmethod
+    def combine(left, right):
+        return Hash(bytes(default_engine().hash_combine_pairs(np.frombuffer(left.bytes + right.bytes, dtype=np.uint8))[0]))
+
+    def to_hex(self):
+        return self.bytes.hex()
+
+
+class MerkleTree:
+    """src/merkle.rs:4-97; the tree lives on the device."""
+
+    def __init__(self, leaves):
+        arr = np.frombuffer(b"".join(h.bytes for h in leaves), dtype=np.uint8).reshape(-1, 32) if leaves else np.zeros((0, 32), np.uint8)
+        self._t = default_engine().merkle_new(arr)
+        self.leaves = list(leaves)
+        self.root = Hash(self._t.root())
+
+    new = classmethod(lambda cls, leaves: cls(leaves))
+
+    @property
+    def nodes(self):
+        """`nodes` of merkle.rs:6: every level, leaves first."""
+        lv, n, out = 0, len(self.leaves), []
+        while n >= 1:
+            out.append([Hash(bytes(r)) for r in self._t.level(lv)])
+            lv, n = lv + 1, n // 2
+        return out
+
+    def get_root(self):
+        return self.root
+
+    @staticmethod
+    def commit(leaves):
+        arr = np.frombuffer(b"".join(h.bytes for h in leaves), dtype=np.uint8).reshape(-1, 32) if leaves else np.zeros((0, 32), np.uint8)
+        return Hash(default_engine().merkle_commit(arr))
+
+    def open(self, index):
+        return [Hash(p) for p in self._t.open(index)]
+
+    @staticmethod
+    def verify(leaf, index, proof, root):
+        cur, idx = leaf, index                                          # merkle.rs:82-96
+        for sib in proof:
+            cur = Hash.combine(cur, sib) if idx % 2 == 0 else Hash.combine(sib, cur)
+            idx //= 2
+        return cur == root
+
+
+class FiatShamir:
+    """src/fiat_shamir.rs:4-26"""
+
+    def __init__(self):
+        self.transcript = bytearray()
+
+    new = classmethod(lambda cls: cls())
+
+    def absorb(self, data: bytes):
+        self.transcript += bytes(data)
+
+    def challenge(self, field):
+        h = default_engine().hash_bytes(bytes(self.transcript))
+        return field.new_element(int.from_bytes(h[:8], "little"))      # unreduced (H6)
+
+
+class ProofObject:
+    """src/stream.rs:8-14"""
+    MERKLE_ROOT, FIELD_ELEMENT, FIELD_ELEMENTS, MERKLE_PATH = 0, 1, 2, 3
+
+    def __init__(self, tag, payload):
+        self.tag, self.payload = tag, payload
+
+    def __repr__(self):
+        return f"ProofObject({self.tag}, ...)"
+
+
+class ProofStream:
+    """src/stream.rs:4-168 (wire format: tags 0-3, LE u64 lengths/values, raw 32-byte digests)."""
+
+    def __init__(self):
+        self.objects = []
+
+    new = classmethod(lambda cls: cls())
+
+    def push(self, obj):
+        self.objects.append(obj)
+
+    def pop(self):
+        return self.objects.pop(0) if self.objects else None
+
+    def serialize(self) -> bytes:
+        out = bytearray()
+        for o in self.objects:
+            out.append(o.tag)
+            if o.tag == 0:
+                out += o.payload.bytes
+            elif o.tag == 1:
+                out += int(o.payload.value).to_bytes(8, "little")
+            elif o.tag == 2:
+                out += len(o.payload).to_bytes(8, "little")
+                for fe in o.payload:
+                    out += int(fe.value).to_bytes(8, "little")
+            else:
+                out += len(o.payload).to_bytes(8, "little")
+                for h in o.payload:
+                    out += h.bytes
+        return bytes(out)
+
+    @staticmethod
+    def deserialize(data: bytes, field):
+        s, i, n = ProofStream(), 0, len(data)
+        while i < n:
+            tag = data[i]
+            i += 1
+            if tag == 0:
+                if i + 32 <= n:
+                    s.push(ProofObject(0, Hash(data[i:i + 32])))
+                    i += 32
+            elif tag == 1:
+                if i + 8 <= n:
+                    s.push(ProofObject(1, field.new_element(int.from_bytes(data[i:i + 8], "little"))))
+                    i += 8
+            elif tag == 2:
+                if i + 8 <= n:
+                    cnt = int.from_bytes(data[i:i + 8], "little")
+                    i += 8
+                    fes = []
+                    for _ in range(min(cnt, (n - i) // 8)):
+                        fes.append(field.new_element(int.from_bytes(data[i:i + 8], "little")))
+                        i += 8
+                    s.push(ProofObject(2, fes))
+            elif tag == 3:
+                if i + 8 <= n:
+                    cnt = int.from_bytes(data[i:i + 8], "little")
+                    i += 8
+                    path = []
+                    for _ in range(min(cnt, (n - i) // 32)):
+                        path.append(Hash(data[i:i + 32]))
+                        i += 32
+                    s.push(ProofObject(3, path))
+            else:
+                break
+        return s
+
+
+class Fri:
+    """src/fri.rs:8-311 (prover side).  Verification stays with the reference's CPU code (it is
+    tiny and host-side); the tests use the oracle's restatement of Fri::verify."""
+
+    def __init__(self, omega, offset, domain_length, expansion_factor, num_colinearity_tests):
+        self.field = omega.field
+        self._eng = self.field.engine()
+        self._cfg = self._eng.fri_cfg(omega.value, offset.value, domain_length, expansion_factor, num_colinearity_tests)
+        self.omega, self.offset = omega, offset
+        self.domain_length, self.expansion_factor, self.num_colinearity_tests = domain_length, expansion_factor, num_colinearity_tests
+
+    new = classmethod(lambda cls, *a: cls(*a))
+
+    def num_rounds(self):
+        return self._eng.fri_num_rounds(self._cfg)
+
+    def fold_codeword(self, codeword, alpha, offset, omega):
+        out = self._eng.fri_fold(_vals(codeword), alpha.value, offset.value, omega.value)
+        return [FieldElement(int(v), self.field) for v in out]
+
+    def eval_domain(self, rnd=0):
+        p = self.field.p                                               # fri.rs:158-166
+        return [FieldElement(self.offset.value * pow(self.omega.value, (1 << rnd) * i, p) % p, self.field)
+                for i in range(self.domain_length >> rnd)]
+
+    def commit(self, initial_codeword, proof_stream, fiat_shamir):
+        """fri.rs:105-156.  Returns the codewords' final element (the last codeword); roots are
+        pushed to the proof stream and absorbed, like the reference."""
+        if fiat_shamir.transcript:
+            raise StarkMiError(-50, "bad argument: the device transcript starts empty (fresh FiatShamir)")
+        roots, alphas, last = self._eng.fri_commit(self._cfg, _vals(initial_codeword))
+        for r in roots:
+            proof_stream.push(ProofObject(0, Hash(bytes(r))))
+            fiat_shamir.absorb(bytes(r))
+        last_fe = [FieldElement(int(v), self.field) for v in last]
+        proof_stream.push(ProofObject(2, last_fe))
+        return last_fe
+
+    def prove(self, initial_codeword, fiat_shamir, proof_stream):
+        """fri.rs:250-311: fills proof_stream, absorbs the roots into fiat_shamir, returns the
+        top-level indices."""
+        if fiat_shamir.transcript:
+            raise StarkMiError(-50, "bad argument: the device transcript starts empty (fresh FiatShamir)")
+        proof, top = self._eng.fri_prove(self._cfg, _vals(initial_codeword))
+        for obj in ProofStream.deserialize(proof, self.field).objects:
+            proof_stream.push(obj)
+            if obj.tag == 0:
+                fiat_shamir.absorb(obj.payload.bytes)
+        return top
+
+
+class Trace:
+    """src/trace.rs:3-50"""
+
+    def __init__(self, trace):
+        self.trace = [list(r) for r in trace]
+        self.num_columns = len(self.trace[0])
+
+    new = classmethod(lambda cls, t: cls(t))
+
+    def get_row(self, i):
+        return self.trace[i] if 0 <= i < len(self.trace) else None
+
+    def get_col(self, j):
+        return [r[j] for r in self.trace]
+
+    def get(self, i, j):
+        try:
+            return self.trace[i][j]
+        except IndexError:
+            return None
+
+    def to_field_elements(self, field):
+        return [[field.new_element(e & 0xFFFFFFFFFFFFFFFF) for e in r] for r in self.trace]   # `e as u64`, unreduced
+
+    @staticmethod
+    def fibonacci(length):
+        a, b, rows = 1, 1, []
+        for _ in range(length):
+            rows.append([a])
+            a, b = b, a + b
+        return Trace(rows)
+
+    def lde(self, field, log_blowup, lde_offset=None):
+        """Build-defined: column-major low-degree extension of the whole trace on
+        the device -- per column interpolate on the trace subgroup, evaluate on the coset."""
+        eng = field.engine()
+        rows = b"".join(int(v & ((1 << 128) - 1)).to_bytes(16, "little") for r in self.trace for v in r)
+        cols = eng.trace_pack(rows, len(self.trace), self.num_columns)
+        return eng.lde(cols, log_blowup, 1, lde_offset)
