@@ -127,7 +127,11 @@ int launch_merkle(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_no
     uint32_t lvl = 0;
     size_t count = n;
     bool from_elems = d_elems != nullptr;
-    const uint32_t KMAX = 2;
+    static const uint32_t KMAX = [] {  // levels fused per launch (tuning knob; LDS stash = 8 KB << K)
+        const char *e = getenv("SMI_MERKLE_K");
+        const int k = e ? atoi(e) : 2;
+        return (uint32_t)(k < 1 ? 1 : (k > 3 ? 3 : k));
+    }();
     if (from_elems && depth == 0) return launch_leaf_hash(ctx, d_elems, 1, d_nodes);
     while (lvl < depth || from_elems) {
         uint32_t K = depth - lvl < KMAX ? depth - lvl : KMAX;

@@ -37,24 +37,65 @@ namespace hashc {
      0x5e, 0xbc, 0x63, 0xc6, 0x97, 0x35, 0x6a, 0xd4, 0xb3, 0x7d, 0xfa, 0xef, 0xc5, 0x91, 0x39, 0x72}
 
 struct Consts {
-    uint32_t J[16];   // J_0 = 0, J_w + J_{w+1} = RC pair of word w (per lane, mod 256)
-    uint32_t lo15;    // RC[15]
-    uint32_t hi15;    // RC[31] - RC[0] - RC[30]  (mod 256, kept positive)
+    uint32_t rc[16];     // round-constant pair of word w: RC[w] | RC[w+16] << 16
+    uint32_t rc502[16];  // 502 * RC per 16-bit lane (mod 2^16): the S-box addend that applies a pending RC
 };
 constexpr Consts make_consts() {
     const uint8_t rc[32] = SMI_RC;
     Consts c{};
-    uint32_t jl = 0, jh = 0;  // J_w lanes
     for (int w = 0; w < 16; w++) {
-        c.J[w] = jl | (jh << 16);
-        jl = (uint32_t)(rc[w] - jl) & 0xFFu;
-        jh = (uint32_t)(rc[w + 16] - jh) & 0xFFu;
+        c.rc[w] = (uint32_t)rc[w] | ((uint32_t)rc[w + 16] << 16);
+        c.rc502[w] = ((502u * rc[w]) & 0xFFFFu) | (((502u * rc[w + 16]) & 0xFFFFu) << 16);
     }
-    c.lo15 = rc[15];
-    c.hi15 = (uint32_t)(rc[31] + 512 - rc[0] - rc[30]) & 0xFFu;
     return c;
 }
 
+// a*m + c on the two 16-bit lanes independently (v_pk_mad_u16): dirt above bit 7 of a lane never
+// reaches the other lane, and the low 9 bits of lane*502 depend only on the lane's low 8 bits.
+SMI_HD uint32_t pk_mad_u16(uint32_t a, uint32_t m, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const us2 r = __builtin_bit_cast(us2, a) * __builtin_bit_cast(us2, m) + __builtin_bit_cast(us2, c);
+    return __builtin_bit_cast(uint32_t, r);
+#else
+    const uint32_t lo = ((a & 0xFFFFu) * (m & 0xFFFFu) + (c & 0xFFFFu)) & 0xFFFFu;
+    const uint32_t hi = ((a >> 16) * (m >> 16) + (c >> 16)) & 0xFFFFu;
+    return lo | (hi << 16);
+#endif
+}
+
+// (mask & a) | (~mask & b) and a + b + c as single VALU ops (the compiler otherwise splits them).
+SMI_HD uint32_t bfi32(uint32_t mask, uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(mask), "v"(a), "v"(b));
+    return r;
+#else
+    return (mask & a) | (~mask & b);
+#endif
+}
+SMI_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;  // gfx950 three-input bit op; 0x96 is the (operand-order independent) parity table
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    return a ^ b ^ c;
+#endif
+}
+SMI_HD uint32_t add3(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    return a + b + c;
+#endif
+}
+
+// State convention: the TRUE state byte is (stored lane + pending round constant) mod 256, where
+// the round constants of the previous mix (src/hash.rs:83-85) may still be pending; only the low 8
+// bits of a lane are meaningful (bits 8..15 may hold carry dirt below 2^16).
 struct State {
     uint32_t s[16];
 };
@@ -65,47 +106,57 @@ SMI_HD void init(State &st) {
     for (int w = 0; w < 16; w++) st.s[w] = (uint32_t)pr[w] * 0x00010001u;  // bytes w and w+16 are both PRIMES[w]
 }
 
-// src/hash.rs:59-86 on clean lanes (each lane <= 255); leaves clean lanes.
-SMI_HD void mix(State &st) {
+// Apply the pending round constants (needed before absorbing or reading the digest).
+SMI_HD void flush(State &st) {
+    constexpr Consts C = make_consts();
+#pragma unroll
+    for (int w = 0; w < 16; w++) st.s[w] += C.rc[w];
+}
+
+// src/hash.rs:59-86.  PENDING: the previous mix's round constants have not been added yet (they
+// are folded into this S-box's multiply-add).  Leaves its own round constants pending.
+template <bool PENDING> SMI_HD void mix_t(State &st) {
     constexpr Consts C = make_consts();
     uint32_t *s = st.s;
-    // (1) S-box: t = 502*b; rotl1(251*b mod 256) = (t & 0xFE) | bit 8 of t.  XOR 0x63 is deferred
-    // through the linear layer (it XORs three bytes, so the constant passes through unchanged).
+    // (1) S-box  rotl1(251*b) (^0x63 deferred): t = 502*(b + rc); result = (t & 0xFE) | bit 8 of t.
+    // Bits 8..15 of the result lanes are left dirty; the linear layer's last XOR masks them.
+    uint32_t r[16];
 #pragma unroll
     for (int w = 0; w < 16; w++) {
-        const uint32_t t = SMI_MUL24(s[w], 502u);
-        s[w] = (t & 0x00FE00FEu) | ((t >> 8) & 0x00010001u);
+        const uint32_t t = pk_mad_u16(s[w], 0x01F601F6u, PENDING ? C.rc502[w] : 0u);
+        r[w] = bfi32(0x00FE00FEu, t, t >> 8);
     }
-    // (2) linear mix: new = (t0^t1^t2^t3) ^ {t2, t1, t3, t0}, then the deferred ^0x63
+    // (2) linear mix: new = (t0^t1^t2^t3) ^ {t2, t1, t3, t0}, with the deferred ^0x63 (it passes
+    // through the three-byte XORs unchanged); the final XOR also masks the lanes clean.
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const uint32_t t0 = s[4 * q], t1 = s[4 * q + 1], t2 = s[4 * q + 2], t3 = s[4 * q + 3];
-        const uint32_t T = t0 ^ t1 ^ t2 ^ t3 ^ 0x00630063u;
-        s[4 * q] = T ^ t2;
-        s[4 * q + 1] = T ^ t1;
-        s[4 * q + 2] = T ^ t3;
-        s[4 * q + 3] = T ^ t0;
+        const uint32_t t0 = r[4 * q], t1 = r[4 * q + 1], t2 = r[4 * q + 2], t3 = r[4 * q + 3];
+        const uint32_t T = xor3(xor3(t0, t1, t2), t3, 0x00630063u);
+        s[4 * q] = (T ^ t2) & 0x00FF00FFu;
+        s[4 * q + 1] = (T ^ t1) & 0x00FF00FFu;
+        s[4 * q + 2] = (T ^ t3) & 0x00FF00FFu;
+        s[4 * q + 3] = (T ^ t0) & 0x00FF00FFu;
     }
-    // (3) ring add as a prefix sum + (4) round constants
+    // (3) ring add as a prefix sum (round constants stay pending)
     const uint32_t old0 = s[0] & 0xFFFFu, old16 = s[0] >> 16, old31 = s[15] >> 16;
     const uint32_t c = old31 + 256u - old0;  // old[31] - old[0] mod 256, positive
-    const uint32_t cc = c * 0x00010001u;
     uint32_t S[16];
     S[0] = s[0];
 #pragma unroll
     for (int w = 1; w < 16; w++) S[w] = S[w - 1] + s[w];       // lane0: P[w]; lane1: P[16+w] - P[15]
     const uint32_t p15 = S[15] & 0xFFFFu;
-    const uint32_t p15s = p15 << 16;
-    uint32_t G[16];
+    const uint32_t E = c * 0x00010001u + (p15 << 17);          // lane0: c; lane1: c + 2*P[15]
 #pragma unroll
-    for (int w = 0; w < 16; w++) G[w] = S[w] + p15s + C.J[w];  // lanes: P[w]+J, P[16+w]+J
-#pragma unroll
-    for (int w = 0; w < 15; w++) s[w] = G[w] + G[w + 1] + cc;  // new[w], new[16+w] incl. round constants
-    const uint32_t lo = 2u * p15 + old16 + c + C.lo15;          // new[15] = P[15] + P[16] + c
-    const uint32_t hi = old31 + (s[0] & 0xFFFFu) + (s[14] >> 16) + C.hi15;  // new[31]
-    s[15] = (lo & 0xFFu) | (hi << 16);
-#pragma unroll
-    for (int w = 0; w < 16; w++) s[w] &= 0x00FF00FFu;
+    for (int w = 0; w < 15; w++) s[w] = add3(S[w], S[w + 1], E);  // new[w] | new[16+w]   (lanes < 2^15)
+    const uint32_t lo = 2u * p15 + old16 + c;                   // new[15] = P[15] + P[16] + c
+    const uint32_t hi = old31 + (s[0] & 0xFFFFu) + (s[14] >> 16);  // new[31] = old[31] + new[0] + new[30]
+    s[15] = lo | (hi << 16);
+}
+
+// One complete mix_state on a fully applied state (used by the single-lane transcript kernels).
+SMI_HD void mix(State &st) {
+    mix_t<false>(st);
+    flush(st);
 }
 
 // byte accessors in the paired-lane layout
@@ -140,6 +191,12 @@ SMI_HD void absorb_chunk32(State &st, const uint32_t m[8]) {
     for (int i = 0; i < 32; i++) absorb_byte(st, i, (m[i >> 2] >> (8 * (i & 3))) & 0xFFu);
     mix(st);
 }
+// same, leaving the round constants of the mix pending (callers continue with mix_t<true>)
+SMI_HD void absorb_chunk32_pending(State &st, const uint32_t m[8]) {
+#pragma unroll
+    for (int i = 0; i < 32; i++) absorb_byte(st, i, (m[i >> 2] >> (8 * (i & 3))) & 0xFFu);
+    mix_t<false>(st);
+}
 
 // Hash::from_field_elements(&[v as u64]) (src/hash.rs:32-35 as used by src/fri.rs:118-121):
 // 8 message bytes (LE u64 of a u32 residue: the upper four are zero), 1 + 8 mixes.
@@ -148,9 +205,10 @@ SMI_HD void leaf_hash(uint32_t v, uint32_t d[8]) {
     init(st);
 #pragma unroll
     for (int i = 0; i < 8; i++) absorb_byte(st, i, i < 4 ? ((v >> (8 * i)) & 0xFFu) : 0u);
-    mix(st);
+    mix_t<false>(st);
 #pragma unroll 1
-    for (int k = 0; k < 8; k++) mix(st);
+    for (int k = 0; k < 8; k++) mix_t<true>(st);
+    flush(st);
     to_words(st, d);
 }
 
@@ -159,9 +217,10 @@ SMI_HD void node_hash(const uint32_t l[8], const uint32_t r[8], uint32_t d[8]) {
     State st;
     init(st);
     absorb_chunk32(st, l);
-    absorb_chunk32(st, r);
+    absorb_chunk32_pending(st, r);
 #pragma unroll 1
-    for (int k = 0; k < 8; k++) mix(st);
+    for (int k = 0; k < 8; k++) mix_t<true>(st);
+    flush(st);
     to_words(st, d);
 }
 
