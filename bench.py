@@ -209,6 +209,7 @@ def main():
 
         # ---- BASELINE configs[3]: 2^26-point four-step NTT sharded over the N GPUs
         if distributed:
+          try:
             lr, lc = 13, 13
             fs = FourStepNTT(HipBackend(eng), lr, lc, p, rank, world)
             ncl = (1 << lc) // world
@@ -227,6 +228,8 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             result["four_step_2p26"] = {"field_elements_per_s": reps * (1 << 26) / float(tt.item()),
                                         "ms_per_transform": 1e3 * float(tt.item()) / reps, "scaling": "strong"}
+          except Exception as e:  # an extra: never lose the headline line over it
+            result["four_step_error"] = str(e)
 
         if rank == 0 and world == 1:
             result["cpu_baseline"] = cpu_baseline()
