@@ -3,7 +3,7 @@
 
 Metric (BASELINE.json): NTT field-elements/s on the 2^22-row trace at blowup 8 (+ prove time).
 Workload at every N: each rank holds its own 4-column x 2^22-row synthetic trace resident in HBM
-(u32 residues of the second prime 2013265921 = 15*2^27+1, because the reference prime
+(u32 residues of the second prime 469762049 = 7*2^26+1, because the reference prime
 998244353 has no 2^25 domain -- SURVEY F2/H1).  One step = the batched low-degree extension of
 that trace: 4 inverse NTTs of 2^22 points + 4 coset NTTs of 2^25 points.  Columns are independent
 units, so ranks share no data-path collective (weak scaling); value = NTT points transformed by

@@ -54,7 +54,7 @@ enum {
     /* contract violations that have no reference counterpart */
     SMI_ERR_BAD_ARG = -50,
     SMI_ERR_NON_CANONICAL = -51,      /* a field value >= p where the precondition forbids it (H6) */
-    SMI_ERR_UNSUPPORTED_PRIME = -52,  /* p must be an odd prime < 2^31 with p-1 divisible by the sizes used */
+    SMI_ERR_UNSUPPORTED_PRIME = -52,  /* p must be an odd prime < 2^30 with p-1 divisible by the sizes used */
     SMI_ERR_NOT_GEOMETRIC = -53,      /* domain is not offset*omega^k: caller must fall back to the CPU code */
     /* runtime */
     SMI_ERR_HIP = -100,
@@ -72,7 +72,7 @@ const char *smi_version(void);
 
 /* ---- context -------------------------------------------------------------------- */
 /* FiniteField::new(p) (src/ff.rs:109-111) plus the generator g() (src/ff.rs:191-197):
- * (998244353, 3) is the reference field; (2013265921, 31) is the build's second prime
+ * (998244353, 3) is the reference field; (469762049, 3) is the build's second prime
  * for domains above 2^23.  device = HIP device ordinal. */
 int smi_ctx_create(uint64_t p, uint64_t g, int device, smi_ctx **out);
 void smi_ctx_destroy(smi_ctx *ctx);

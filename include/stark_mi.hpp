@@ -1,0 +1,405 @@
+// stark_mi.hpp -- header-only C++17 host mirror of the reference's types over the C ABI.
+//
+// The reference is Rust (0xSooki/stark-rs) and the build image has no Rust toolchain, so the host
+// side above the C ABI is written in C++: the same names, argument meaning and error behaviour as
+// the reference's `FiniteField`, `FieldElement`, `Polynomial`, `Hash`, `MerkleTree`, `FiatShamir`,
+// `ProofStream`, `Fri`, `Trace` for the hot path, with every heavy method a call into
+// libstarkmi.so (include/stark_mi.h).  A reference panic becomes starkmi::Panic whose what() is
+// the reference's message.  tests/cpp/fri_mirror_test.cpp replays src/fri.rs:533-693 on it.
+#pragma once
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "stark_mi.h"
+
+namespace starkmi {
+
+struct Panic : std::runtime_error {
+    int status;
+    Panic(int s, const std::string &m) : std::runtime_error(m), status(s) {}
+};
+
+inline void check(int status, const smi_ctx *ctx = nullptr) {
+    if (status == SMI_OK) return;
+    std::string msg = smi_status_string(status);
+    if (ctx && status <= SMI_ERR_BAD_ARG) msg += std::string(": ") + smi_last_error(ctx);
+    throw Panic(status, msg);
+}
+
+// One GPU context per modulus, created on first use (single-owner, like the Rust binding's thread_local).
+inline smi_ctx *context(uint64_t p) {
+    static smi_ctx *ref = nullptr, *second = nullptr;
+    smi_ctx **slot = p == 998244353ull ? &ref : &second;
+    if (!*slot) check(smi_ctx_create(p, 3, 0, slot));
+    return *slot;
+}
+
+struct FieldElement;
+
+// src/ff.rs:9-12, 108-233
+struct FiniteField {
+    uint64_t p;
+    explicit FiniteField(uint64_t p_ = 998244353ull) : p(p_) {}
+    bool operator==(const FiniteField &o) const { return p == o.p; }
+    uint64_t modulus() const { return p; }
+    inline FieldElement new_element(uint64_t v) const;
+    inline FieldElement zero() const;
+    inline FieldElement one() const;
+    inline FieldElement add(const FieldElement &l, const FieldElement &r) const;
+    inline FieldElement sub(const FieldElement &l, const FieldElement &r) const;
+    inline FieldElement mul(const FieldElement &l, const FieldElement &r) const;
+    inline FieldElement neg(const FieldElement &x) const;
+    inline FieldElement inv(const FieldElement &x) const;
+    inline FieldElement div(const FieldElement &l, const FieldElement &r) const;
+    inline FieldElement exp(const FieldElement &b, uint64_t e) const;
+    inline FieldElement g() const;
+    inline FieldElement prim_nth_root(uint64_t n) const;
+    smi_ctx *ctx() const { return context(p); }
+};
+
+// src/ff.rs:24-28
+struct FieldElement {
+    uint64_t value;
+    FiniteField field;
+    bool operator==(const FieldElement &o) const { return value == o.value && field == o.field; }
+    bool operator!=(const FieldElement &o) const { return !(*this == o); }
+    FieldElement operator+(const FieldElement &o) const { return field.add(*this, o); }
+    FieldElement operator-(const FieldElement &o) const { return field.sub(*this, o); }
+    FieldElement operator*(const FieldElement &o) const { return field.mul(*this, o); }
+    FieldElement operator/(const FieldElement &o) const { return field.div(*this, o); }
+    FieldElement pow(uint64_t e) const { return field.exp(*this, e); }
+};
+
+inline FieldElement FiniteField::new_element(uint64_t v) const { return FieldElement{v, *this}; }  // unreduced, ff.rs:113-118
+inline FieldElement FiniteField::zero() const { return FieldElement{0, *this}; }
+inline FieldElement FiniteField::one() const { return FieldElement{1, *this}; }
+inline FieldElement FiniteField::add(const FieldElement &l, const FieldElement &r) const {
+    return {(uint64_t)(((unsigned __int128)l.value + r.value) % p), *this};
+}
+inline FieldElement FiniteField::sub(const FieldElement &l, const FieldElement &r) const {
+    return {(uint64_t)((((unsigned __int128)p + l.value) - r.value) % p), *this};
+}
+inline FieldElement FiniteField::mul(const FieldElement &l, const FieldElement &r) const {
+    return {(uint64_t)(((unsigned __int128)l.value * r.value) % p), *this};
+}
+inline FieldElement FiniteField::neg(const FieldElement &x) const { return {(p - x.value) % p, *this}; }
+inline FieldElement FiniteField::inv(const FieldElement &x) const {
+    uint64_t out = 0;
+    check(smi_ff_inv(ctx(), x.value, &out));  // "no inverse", ff.rs:171
+    return {out, *this};
+}
+inline FieldElement FiniteField::div(const FieldElement &l, const FieldElement &r) const {
+    if (r.value == 0) throw Panic(SMI_ERR_DIV_BY_ZERO, smi_status_string(SMI_ERR_DIV_BY_ZERO));
+    return mul(l, inv(r));
+}
+inline FieldElement FiniteField::exp(const FieldElement &b, uint64_t e) const {
+    uint64_t out = 0;
+    check(smi_ff_exp(ctx(), b.value, e, &out));
+    return {out, *this};
+}
+inline FieldElement FiniteField::g() const {
+    if (p != 998244353ull) throw Panic(SMI_ERR_WRONG_FIELD, smi_status_string(SMI_ERR_WRONG_FIELD));  // ff.rs:192
+    return {3, *this};
+}
+inline FieldElement FiniteField::prim_nth_root(uint64_t n) const {
+    if (p != 998244353ull) throw Panic(SMI_ERR_WRONG_FIELD, smi_status_string(SMI_ERR_WRONG_FIELD));  // ff.rs:216
+    uint64_t out = 0;
+    check(smi_prim_nth_root(ctx(), n, &out));
+    return {out, *this};
+}
+
+inline std::vector<uint64_t> values_of(const std::vector<FieldElement> &v) {
+    std::vector<uint64_t> out(v.size());
+    for (size_t i = 0; i < v.size(); i++) out[i] = v[i].value;
+    return out;
+}
+inline std::vector<FieldElement> elements_of(const std::vector<uint64_t> &v, const FiniteField &f) {
+    std::vector<FieldElement> out;
+    out.reserve(v.size());
+    for (uint64_t x : v) out.push_back(f.new_element(x));
+    return out;
+}
+inline uint32_t log2_exact(size_t n) {
+    uint32_t l = 0;
+    while (((size_t)1 << l) < n) l++;
+    return l;
+}
+
+// src/univariate/mod.rs:8-153, interpolate.rs, eval.rs
+struct Polynomial {
+    std::vector<FieldElement> coeffs;
+    FiniteField field;
+    Polynomial(std::vector<FieldElement> c, FiniteField f) : coeffs(std::move(c)), field(f) {}
+    long deg() const {
+        long d = -1;
+        for (size_t i = 0; i < coeffs.size(); i++)
+            if (coeffs[i].value != 0) d = (long)i;
+        return d;
+    }
+    bool is_zero() const { return deg() == -1; }
+    bool operator==(const Polynomial &o) const {  // mod.rs:13-39: trailing zeros ignored
+        if (deg() != o.deg()) return false;
+        for (long i = 0; i <= deg(); i++)
+            if (coeffs[i] != o.coeffs[i]) return false;
+        return true;
+    }
+    FieldElement eval(const FieldElement &x) const {  // eval.rs:6-14 (single point: host)
+        FieldElement xi = field.one(), val = field.zero();
+        for (const FieldElement &c : coeffs) {
+            val = val + c * xi;
+            xi = xi * x;
+        }
+        return val;
+    }
+    // eval.rs:16-21 on a geometric domain offset*omega^k (the fast-path contract)
+    std::vector<FieldElement> eval_domain(const std::vector<FieldElement> &domain) const {
+        if (domain.empty()) return {};
+        const FiniteField f = domain[0].field;
+        std::vector<uint64_t> d = values_of(domain);
+        uint64_t offset = 0;
+        check(smi_domain_is_geometric(f.ctx(), d.data(), d.size(), &offset));
+        const size_t nc = (size_t)(deg() + 1);
+        std::vector<uint64_t> c = values_of(coeffs), out(d.size());
+        c.resize(nc);
+        check(smi_coset_ntt(f.ctx(), c.data(), nc, out.data(), log2_exact(d.size()), offset), f.ctx());
+        return elements_of(out, f);
+    }
+    // interpolate.rs:6-44 on a geometric domain
+    static Polynomial interpolate_domain(const std::vector<FieldElement> &domain, const std::vector<FieldElement> &values) {
+        if (domain.size() != values.size()) throw Panic(SMI_ERR_LEN_MISMATCH, smi_status_string(SMI_ERR_LEN_MISMATCH));
+        if (domain.empty()) throw Panic(SMI_ERR_EMPTY_DOMAIN, smi_status_string(SMI_ERR_EMPTY_DOMAIN));
+        const FiniteField f = domain[0].field;
+        std::vector<uint64_t> d = values_of(domain), v = values_of(values), c(v.size());
+        uint64_t offset = 0;
+        check(smi_domain_is_geometric(f.ctx(), d.data(), d.size(), &offset));
+        check(smi_intt(f.ctx(), v.data(), c.data(), log2_exact(v.size()), offset), f.ctx());
+        bool all_zero = true;
+        for (uint64_t x : v) all_zero = all_zero && x == 0;
+        if (v.size() > 1 && all_zero) return Polynomial({}, f);
+        return Polynomial(elements_of(c, f), f);
+    }
+    Polynomial scale(const FieldElement &factor) const {  // mod.rs:99-113
+        std::vector<uint64_t> c = values_of(coeffs), out(c.size());
+        if (!c.empty()) check(smi_poly_scale(field.ctx(), c.data(), c.size(), factor.value % field.p, out.data()), field.ctx());
+        return Polynomial(elements_of(out, field), field);
+    }
+};
+
+// src/hash.rs:1-46
+struct Hash {
+    uint8_t b[32];
+    bool operator==(const Hash &o) const { return std::memcmp(b, o.b, 32) == 0; }
+    bool operator!=(const Hash &o) const { return !(*this == o); }
+    static Hash from_bytes(const uint8_t *data, size_t len) {
+        Hash h;
+        check(smi_hash_bytes(context(998244353ull), data, len, h.b));
+        return h;
+    }
+    static Hash from_field_elements(const std::vector<uint64_t> &e) {
+        std::vector<uint8_t> buf(e.size() * 8);
+        for (size_t i = 0; i < e.size(); i++)
+            for (int k = 0; k < 8; k++) buf[8 * i + k] = (uint8_t)(e[i] >> (8 * k));
+        return from_bytes(buf.data(), buf.size());
+    }
+    static Hash from_u64(uint64_t v) { return from_field_elements({v}); }
+    static Hash combine(const Hash &l, const Hash &r) {
+        uint8_t in[64];
+        std::memcpy(in, l.b, 32);
+        std::memcpy(in + 32, r.b, 32);
+        Hash h;
+        check(smi_hash_combine_pairs(context(998244353ull), in, 1, h.b));
+        return h;
+    }
+};
+
+// src/merkle.rs:4-97; the tree stays on the device
+class MerkleTree {
+    std::shared_ptr<smi_tree> t_;
+    smi_ctx *ctx_;
+
+  public:
+    std::vector<Hash> leaves;
+    Hash root;
+    explicit MerkleTree(const std::vector<Hash> &lv) : ctx_(context(998244353ull)), leaves(lv) {
+        smi_tree *t = nullptr;
+        check(smi_merkle_new(ctx_, lv.empty() ? nullptr : lv[0].b, lv.size(), &t), ctx_);
+        t_.reset(t, smi_merkle_free);
+        check(smi_merkle_root(ctx_, t, root.b), ctx_);
+    }
+    const Hash &get_root() const { return root; }
+    static Hash commit(const std::vector<Hash> &lv) {
+        Hash h;
+        check(smi_merkle_commit(context(998244353ull), lv.empty() ? nullptr : lv[0].b, lv.size(), h.b));
+        return h;
+    }
+    std::vector<Hash> open(size_t index) const {
+        std::vector<Hash> path(64);
+        size_t depth = 0;
+        check(smi_merkle_open(ctx_, t_.get(), index, path[0].b, &depth), ctx_);
+        path.resize(depth);
+        return path;
+    }
+    static bool verify(const Hash &leaf, size_t index, const std::vector<Hash> &proof, const Hash &root) {
+        Hash cur = leaf;  // merkle.rs:82-96
+        for (const Hash &sib : proof) {
+            cur = index % 2 == 0 ? Hash::combine(cur, sib) : Hash::combine(sib, cur);
+            index /= 2;
+        }
+        return cur == root;
+    }
+};
+
+// src/fiat_shamir.rs:4-26
+struct FiatShamir {
+    std::vector<uint8_t> transcript;
+    void absorb(const uint8_t *data, size_t len) { transcript.insert(transcript.end(), data, data + len); }
+    FieldElement challenge(const FiniteField &field) const {
+        Hash h = Hash::from_bytes(transcript.data(), transcript.size());
+        uint64_t v = 0;
+        for (int i = 0; i < 8; i++) v |= (uint64_t)h.b[i] << (8 * i);
+        return field.new_element(v);  // unreduced
+    }
+};
+
+// src/stream.rs:8-14
+struct ProofObject {
+    enum Tag { MerkleRoot = 0, FieldElementTag = 1, FieldElements = 2, MerklePath = 3 } tag;
+    Hash hash{};
+    std::vector<uint64_t> elements;
+    std::vector<Hash> path;
+};
+
+// src/stream.rs:4-168
+struct ProofStream {
+    std::vector<ProofObject> objects;
+    size_t head = 0;
+    void push(ProofObject o) { objects.push_back(std::move(o)); }
+    const ProofObject *pop() { return head < objects.size() ? &objects[head++] : nullptr; }
+    std::vector<uint8_t> serialize() const {
+        std::vector<uint8_t> out;
+        auto put64 = [&](uint64_t v) { for (int i = 0; i < 8; i++) out.push_back((uint8_t)(v >> (8 * i))); };
+        for (const ProofObject &o : objects) {
+            out.push_back((uint8_t)o.tag);
+            switch (o.tag) {
+            case ProofObject::MerkleRoot: out.insert(out.end(), o.hash.b, o.hash.b + 32); break;
+            case ProofObject::FieldElementTag: put64(o.elements[0]); break;
+            case ProofObject::FieldElements: put64(o.elements.size()); for (uint64_t v : o.elements) put64(v); break;
+            case ProofObject::MerklePath: put64(o.path.size()); for (const Hash &h : o.path) out.insert(out.end(), h.b, h.b + 32); break;
+            }
+        }
+        return out;
+    }
+    static ProofStream deserialize(const std::vector<uint8_t> &b) {
+        ProofStream s;
+        size_t i = 0, n = b.size();
+        auto get64 = [&](size_t at) { uint64_t v = 0; for (int k = 0; k < 8; k++) v |= (uint64_t)b[at + k] << (8 * k); return v; };
+        while (i < n) {
+            uint8_t tag = b[i++];
+            ProofObject o;
+            if (tag == 0) {
+                if (i + 32 <= n) { o.tag = ProofObject::MerkleRoot; std::memcpy(o.hash.b, &b[i], 32); i += 32; s.push(o); }
+            } else if (tag == 1) {
+                if (i + 8 <= n) { o.tag = ProofObject::FieldElementTag; o.elements = {get64(i)}; i += 8; s.push(o); }
+            } else if (tag == 2) {
+                if (i + 8 <= n) {
+                    uint64_t len = get64(i); i += 8;
+                    o.tag = ProofObject::FieldElements;
+                    for (uint64_t k = 0; k < len && i + 8 <= n; k++) { o.elements.push_back(get64(i)); i += 8; }
+                    s.push(o);
+                }
+            } else if (tag == 3) {
+                if (i + 8 <= n) {
+                    uint64_t len = get64(i); i += 8;
+                    o.tag = ProofObject::MerklePath;
+                    for (uint64_t k = 0; k < len && i + 32 <= n; k++) { Hash h; std::memcpy(h.b, &b[i], 32); o.path.push_back(h); i += 32; }
+                    s.push(o);
+                }
+            } else break;
+        }
+        return s;
+    }
+};
+
+// src/fri.rs:8-311 (prover side)
+class Fri {
+  public:
+    FieldElement offset, omega;
+    size_t domain_length;
+    FiniteField field;
+    size_t expansion_factor, num_colinearity_tests;
+    Fri(FieldElement omega_, FieldElement offset_, size_t domain_length_, size_t expansion_factor_, size_t t)
+        : offset(offset_), omega(omega_), domain_length(domain_length_), field(omega_.field), expansion_factor(expansion_factor_),
+          num_colinearity_tests(t) {
+        cfg_ = smi_fri_cfg{omega.value, offset.value, domain_length, expansion_factor, t};
+        check(smi_fri_check(field.ctx(), &cfg_));  // asserts of fri.rs:37-45
+    }
+    uint64_t num_rounds() const {
+        uint64_t r = 0;
+        check(smi_fri_num_rounds(&cfg_, &r));
+        return r;
+    }
+    std::vector<FieldElement> fold_codeword(const std::vector<FieldElement> &cw, const FieldElement &alpha, const FieldElement &off,
+                                            const FieldElement &om) const {
+        std::vector<uint64_t> in = values_of(cw), out(cw.size() / 2);
+        check(smi_fri_fold(field.ctx(), in.data(), in.size(), alpha.value, off.value, om.value, out.data()), field.ctx());
+        return elements_of(out, field);
+    }
+    // fri.rs:250-311: fills proof_stream, absorbs the roots into fiat_shamir, returns the top-level indices
+    std::vector<size_t> prove(const std::vector<FieldElement> &initial_codeword, FiatShamir &fiat_shamir, ProofStream &proof_stream) const {
+        if (!fiat_shamir.transcript.empty()) throw Panic(SMI_ERR_BAD_ARG, "bad argument: the device transcript starts empty");
+        std::vector<uint64_t> cw = values_of(initial_codeword), top(num_colinearity_tests + 1);
+        uint8_t *proof = nullptr;
+        size_t len = 0;
+        check(smi_fri_prove(field.ctx(), &cfg_, cw.data(), cw.size(), &proof, &len, top.data()), field.ctx());
+        std::vector<uint8_t> bytes(proof, proof + len);
+        smi_free(proof);
+        for (const ProofObject &o : ProofStream::deserialize(bytes).objects) {
+            if (o.tag == ProofObject::MerkleRoot) fiat_shamir.absorb(o.hash.b, 32);
+            proof_stream.push(o);
+        }
+        return std::vector<size_t>(top.begin(), top.begin() + num_colinearity_tests);
+    }
+
+  private:
+    smi_fri_cfg cfg_;
+};
+
+// src/trace.rs:3-50
+struct Trace {
+    std::vector<std::vector<__int128>> trace;
+    size_t num_columns;
+    explicit Trace(const std::vector<std::vector<__int128>> &t) : trace(t), num_columns(t[0].size()) {}
+    std::vector<__int128> get_col(size_t j) const {
+        std::vector<__int128> c;
+        for (const auto &r : trace) c.push_back(r[j]);
+        return c;
+    }
+    static Trace fibonacci(size_t length) {
+        std::vector<std::vector<__int128>> rows;
+        __int128 a = 1, b = 1;
+        for (size_t i = 0; i < length; i++) {
+            rows.push_back({a});
+            __int128 next = a + b;
+            a = b;
+            b = next;
+        }
+        return Trace(rows);
+    }
+    // build-defined: column-major low-degree extension on the device
+    std::vector<std::vector<uint64_t>> lde(const FiniteField &f, uint32_t log_blowup, uint64_t lde_offset) const {
+        const size_t n = trace.size();
+        std::vector<__int128> rows;   // row-major i128, the layout of Trace.trace (trace.rs:4-7)
+        for (const auto &r : trace) rows.insert(rows.end(), r.begin(), r.end());
+        std::vector<uint64_t> cols(num_columns * n), out(num_columns * (n << log_blowup));
+        check(smi_trace_pack(f.ctx(), rows.data(), n, num_columns, cols.data()));
+        check(smi_lde(f.ctx(), cols.data(), (uint32_t)num_columns, log2_exact(n), log_blowup, 1, lde_offset, out.data()), f.ctx());
+        std::vector<std::vector<uint64_t>> res(num_columns);
+        for (size_t c = 0; c < num_columns; c++) res[c].assign(out.begin() + c * (n << log_blowup), out.begin() + (c + 1) * (n << log_blowup));
+        return res;
+    }
+};
+
+}  // namespace starkmi

@@ -13,8 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "build", "libstark_oracle.so")
 
 P_REF = 998244353          # src/ff.rs:192
-P2 = 2013265921            # 15*2^27+1, generator 31 (not a reference constant)
-G_REF, G2 = 3, 31
+P2 = 469762049             # 7*2^26+1, generator 3 (not a reference constant)
+G_REF, G2 = 3, 3
 
 
 class OraclePanic(Exception):

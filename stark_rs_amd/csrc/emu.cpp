@@ -5,6 +5,7 @@
 // time, and compare with the oracle.  This catches indexing / twiddle / planning mistakes
 // before GPU time is spent.  The product never loads this library: stark_rs_amd fails
 // loudly without libstarkmi.so and a GPU.
+#include <array>
 #include <vector>
 
 #include "ntt_driver.h"
@@ -16,7 +17,7 @@ std::vector<uint32_t> fill(const GeomSpec &s, const Fp &F) {
     std::vector<uint32_t> t((size_t)s.count << s.pair);
     for (uint32_t i = 0; i < s.count; i++) {
         const uint32_t v = geom_entry(s.c_m, s.q_m, i, s.stride, F);
-        if (s.pair) { t[2 * i] = v; t[2 * i + 1] = v * F.pinv; }
+        if (s.pair) { const Tw2 c = tw2_from_mont(v, F); t[2 * i] = c.w; t[2 * i + 1] = c.q; }
         else t[i] = v;
     }
     return t;
@@ -29,12 +30,18 @@ template <int LOGR, int LOGW, bool LAST> void emu_pass(const PassArgs &a, uint32
     for (uint32_t b = 0; b < batch; b++)
         for (uint32_t blk = 0; blk < a.n_tiles; blk++) {
             typename NP::TileId t = NP::tile_id(a, blk);
-            for (uint32_t tid = 0; tid < (uint32_t)NP::NT; tid++) NP::load_tw(a, tw.data(), tid);
-            for (uint32_t tid = 0; tid < (uint32_t)NP::NT; tid++) NP::load(a, t, b, tile.data(), tid);
-            for (uint32_t tid = 0; tid < (uint32_t)NP::NT; tid++) NP::template step_i<0>(a, tile.data(), tw.data(), tid);
-            for (uint32_t tid = 0; tid < (uint32_t)NP::NT; tid++) NP::template step_i<1>(a, tile.data(), tw.data(), tid);
-            for (uint32_t tid = 0; tid < (uint32_t)NP::NT; tid++) NP::template step_i<2>(a, tile.data(), tw.data(), tid);
-            for (uint32_t tid = 0; tid < (uint32_t)NP::NT; tid++) NP::store(a, t, b, tile.data(), tid);
+            const uint32_t NT = NP::NT;
+            for (uint32_t tid = 0; tid < NT; tid++) NP::load_tw(a, tw.data(), tid);
+            if (!LAST) {
+                std::vector<std::array<uint32_t, 16>> regs(NT);   // per-thread registers live across the barrier
+                for (uint32_t tid = 0; tid < NT; tid++) NP::load_regs(a, t, b, reinterpret_cast<uint32_t(&)[16]>(regs[tid]), tid);
+                for (uint32_t tid = 0; tid < NT; tid++) NP::step0_regs(a, reinterpret_cast<uint32_t(&)[16]>(regs[tid]), tile.data(), tw.data(), tid);
+            } else {
+                for (uint32_t tid = 0; tid < NT; tid++) NP::load_lds(a, t, b, tile.data(), tid);
+                for (uint32_t tid = 0; tid < NT; tid++) NP::step0_lds(a, tile.data(), tw.data(), tid);
+            }
+            for (uint32_t tid = 0; tid < NT; tid++) NP::step_mid(a, tile.data(), tw.data(), tid);
+            for (uint32_t tid = 0; tid < NT; tid++) NP::last_step_store(a, t, b, tile.data(), tw.data(), tid);
         }
 }
 

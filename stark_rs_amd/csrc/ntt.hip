@@ -16,17 +16,22 @@ __global__ __launch_bounds__(1 << (LOGR + LOGW - 4)) void ntt_pass_kernel(const 
     const uint32_t tid = threadIdx.x, batch = blockIdx.y;
     const typename NP::TileId t = NP::tile_id(a, blockIdx.x);
     NP::load_tw(a, tw, tid);
-    NP::load(a, t, batch, tile, tid);
-    __syncthreads();
-    NP::template step_i<0>(a, tile, tw, tid);
-    __syncthreads();
-    NP::template step_i<1>(a, tile, tw, tid);
+    if (!LAST) {
+        uint32_t v[NP::V];
+        NP::load_regs(a, t, batch, v, tid);
+        __syncthreads();                       // twiddle table staged
+        NP::step0_regs(a, v, tile, tw, tid);
+    } else {
+        NP::load_lds(a, t, batch, tile, tid);
+        __syncthreads();
+        NP::step0_lds(a, tile, tw, tid);
+    }
     __syncthreads();
     if (NP::St::n == 3) {
-        NP::template step_i<2>(a, tile, tw, tid);
+        NP::step_mid(a, tile, tw, tid);
         __syncthreads();
     }
-    NP::store(a, t, batch, tile, tid);
+    NP::last_step_store(a, t, batch, tile, tw, tid);
 }
 
 __global__ __launch_bounds__(SMI_NTT_THREADS) void ntt_small_kernel(const SmallArgs a) {
@@ -46,8 +51,9 @@ __global__ void geom_table_kernel(uint32_t *out, GeomSpec s, Fp F) {
     if (i >= s.count) return;
     const uint32_t v = geom_entry(s.c_m, s.q_m, i, s.stride, F);
     if (s.pair) {
-        out[2 * i] = v;
-        out[2 * i + 1] = v * F.pinv;
+        const Tw2 c = tw2_from_mont(v, F);
+        out[2 * i] = c.w;
+        out[2 * i + 1] = c.q;
     } else {
         out[i] = v;
     }

@@ -12,29 +12,38 @@
 // so after the last pass (B = 1) element (k_0,...,k_{np-1}) holds output index
 // K = k_0 + R_0*k_1 + R_0*R_1*k_2 + ...; the last pass writes it there directly.
 //
-// One workgroup = 256 threads = one 4096-element tile = W adjacent lines of R points
-// (R*W = 4096), staged in LDS as [R][W+1].  Lines are W adjacent b-columns (runs of W*4
-// contiguous bytes in HBM) for strided passes, and W rows with adjacent k_0 for the last
-// pass (so its transposed writes are W-element runs too).  Inside the tile the R-point
-// transform is 2-3 register-resident radix-8/16 steps with an LDS exchange between them;
-// twiddles w_R^j are staged in LDS once per workgroup.
+// One workgroup = one tile of W lines x R points (4K..16K points), 16 points per thread.
+// Lines are W adjacent b-columns (runs of W*4 contiguous bytes in HBM) for strided passes,
+// and W rows with adjacent k_0 for the last pass (so its transposed writes are W-element
+// runs too).  The R-point transform is 2-3 register-resident steps (radix 16, then 8/4/16)
+// with an LDS exchange between them.  Strided passes feed the first step straight from
+// their global loads and every pass stores straight from the last step's registers, so a
+// two-step tile crosses LDS once.
+//
+// Arithmetic inside a tile is lazy (Harvey): values live in [0, 2p), p < 2^30;
+//   add:  s = a + b,            min(s, s - 2p)                  -> [0, 2p)
+//   sub:  d = a - b + 2p in (0, 4p) goes straight into a twiddle multiply, or is folded back
+//   mul by a table twiddle (w, wq = floor(w 2^32 / p)):  a*w - hi(a*wq)*p  -> [0, 2p)  (Shoup)
+// and results are made canonical once, at the store.  The reference's arithmetic is exact
+// (`% p` on u128, src/ff.rs:138-160), so canonical residues are bit-identical whatever the
+// intermediate representation.
 #pragma once
 #include "field.h"
 
 #define SMI_TILE_LOG 12          // smallest tile (and the size limit of the single-workgroup kernel)
 #define SMI_TILE (1u << SMI_TILE_LOG)
 #define SMI_NTT_THREADS 256      // threads of the small kernel; pass kernels use tile/16 threads
-#define SMI_TW_LOG 10   // in-tile twiddle table: w_1024^j
+#define SMI_TW_LOG 10            // in-tile twiddle table: w_1024^j
 
-// A table twiddle with its Montgomery companion q = w * p^-1 mod 2^32 (see mont_mul_c).
+// A table twiddle in plain form with its Shoup quotient q = floor(w * 2^32 / p).
 struct alignas(8) Tw2 {
     uint32_t w, q;
 };
 
-struct NttTables {        // per (prime, direction); all values in Montgomery form
-    const Tw2 *tw10;      // w_1024^j, j < 1024
-    const uint32_t *lo;   // W^e,          e < 2^h      (W = primitive 2^K-th root for this direction)
-    const uint32_t *hi;   // W^(e * 2^h),  e < 2^(K-h)
+struct NttTables {        // per (prime, direction)
+    const Tw2 *tw10;      // w_1024^j, j < 1024 (plain + Shoup quotient)
+    const uint32_t *lo;   // W^e,          e < 2^h      (Montgomery form; W = primitive 2^K-th root)
+    const uint32_t *hi;   // W^(e * 2^h),  e < 2^(K-h)  (Montgomery form)
     uint32_t K, h;
 };
 struct ScaleTables {      // c * q^i = lo[i & (2^h-1)] * hi[i >> h]   (Montgomery form)
@@ -60,13 +69,11 @@ struct PassArgs {
     uint32_t n_tiles;  // grid.x
     const Tw2 *ptab;        // inter-pass twiddles w_m^(k*b) at [k*B + b] for passes after the first (else null)
     uint32_t pre_ratio_m;   // q^(T*B): step of the input coset scale between a thread's loads (Montgomery)
-    uint32_t post_ratio_m;  // q^(2^Sp): step of the output scale between a thread's stores (Montgomery)
+    uint32_t post_ratio_m;  // q^((R/r_last) << Sp): step of the output scale between a thread's stores (Montgomery)
 };
 
-// digit structure of the in-tile transform.  s0 = 4 everywhere: in the store phase thread t owns
-// column w = t % W and the 16 positions loc = (t / W) + i * (256 / W), whose leading digit is i, so
-// its frequencies are k = i + 16 * krest -- consecutive, which lets inter-pass twiddles and coset
-// scales be running products instead of per-element table gathers.
+// digit structure of the in-tile transform; s0 = 4 everywhere, so the 16 values a thread loads in
+// a strided pass (rows j0 + i*R/16) are exactly the inputs of its one radix-16 butterfly.
 template <int LOGR> struct Steps;
 template <> struct Steps<6>  { enum { n = 2, s0 = 4, s1 = 2, s2 = 0 }; };
 template <> struct Steps<7>  { enum { n = 2, s0 = 4, s1 = 3, s2 = 0 }; };
@@ -92,9 +99,21 @@ SMI_HD uint32_t two_level(const uint32_t *lo, const uint32_t *hi, uint32_t h, ui
     return mont_mul(lo[e & ((1u << h) - 1u)], hi[e >> h], F);
 }
 
-// S-stage radix-2 DIF on 2^S registers; x[brev(k)] = X_k on return.  cw = w_R^j table in
+// ---- lazy arithmetic on [0, 2p), p < 2^30
+SMI_HD uint32_t lz_add(uint32_t a, uint32_t b, uint32_t p2) {
+    const uint32_t s = a + b;          // < 4p < 2^32
+    return umin32(s, s - p2);          // s - 2p wraps to a huge value exactly when s < 2p
+}
+SMI_HD uint32_t lz_fold(uint32_t d, uint32_t p2) { return umin32(d, d - p2); }   // [0,4p) -> [0,2p)
+SMI_HD uint32_t shoup_mul(uint32_t a, const Tw2 &c, uint32_t p) {               // any a < 2^32 -> [0,2p)
+    return a * c.w - umulhi32(a, c.q) * p;
+}
+SMI_HD uint32_t lz_canon(uint32_t a, uint32_t p) { return umin32(a, a - p); }  // [0,2p) -> [0,p)
+
+// S-stage radix-2 DIF on 2^S registers, lazy; x[brev(k)] = X_k on return.  cw = w_R^j table in
 // LDS, croot_shift = LOGR - S so that w_r^j = cw[j << croot_shift].
 template <int S> SMI_HD void dft_regs(uint32_t (&x)[1 << S], const Tw2 *cw, int croot_shift, const Fp &F) {
+    const uint32_t p2 = 2u * F.p;
 #pragma unroll
     for (int s = 0; s < S; s++) {
         const int half = (1 << S) >> (s + 1);
@@ -102,27 +121,28 @@ template <int S> SMI_HD void dft_regs(uint32_t (&x)[1 << S], const Tw2 *cw, int 
         for (int i = 0; i < (1 << S); i++) {
             if (i & half) continue;
             const int j = i | half;
-            uint32_t u = x[i], v = x[j];
-            x[i] = fp_add(u, v, F.p);
-            uint32_t d = fp_sub(u, v, F.p);
-            const int e = (i & (half - 1)) << s;  // w_{2half}^pos = w_r^(pos << s)
-            if (e) {
-                const Tw2 c = cw[e << croot_shift];
-                d = mont_mul_c(d, c.w, c.q, F);
-            }
-            x[j] = d;
+            const uint32_t u = x[i], v = x[j];
+            x[i] = lz_add(u, v, p2);
+            const uint32_t d = u - v + p2;          // (0, 4p)
+            const int e = (i & (half - 1)) << s;    // w_{2half}^pos = w_r^(pos << s)
+            x[j] = e ? shoup_mul(d, cw[e << croot_shift], F.p) : lz_fold(d, p2);
         }
     }
 }
 
 // A tile is R = 2^LOGR points x W = 2^LOGW lines, 16 points per thread (NT = R*W/16 threads).
+//
+// Tile program (sync = workgroup barrier; the emulator runs each phase for every thread first):
+//   strided pass: load_tw, load_regs | sync | step0_regs | sync | [step_mid | sync] | last_step_store
+//   last pass:    load_tw, load_lds  | sync | step0_lds  | sync | [step_mid | sync] | last_step_store
 template <int LOGR, int LOGW, bool LAST> struct NttPass {
     enum { TILE_LOG = LOGR + LOGW, TILE = 1 << TILE_LOG, NT = TILE / 16, R = 1 << LOGR, W = 1 << LOGW, WP = W + 1, V = 16 };
     typedef Steps<LOGR> St;
+    enum { SL = St::n == 2 ? St::s1 : St::s2, RL = 1 << SL };   // radix of the last step
 
     struct TileId {  // wave-uniform description of the tile this workgroup owns
         uint64_t in_base, out_base;  // element offsets of line 0 / output run 0 (within the column)
-        uint32_t b0;                 // first inner column (strided passes)
+        uint32_t b0;                 // first inner column (strided passes) / first k_0 (last pass)
     };
 
     static SMI_HD TileId tile_id(const PassArgs &a, uint32_t block) {
@@ -164,59 +184,71 @@ template <int LOGR, int LOGW, bool LAST> struct NttPass {
         }
     }
 
-    static SMI_HD void load(const PassArgs &a, const TileId &t, uint32_t batch, uint32_t *tile, uint32_t tid) {
-        // wave-uniform base pointer + 32-bit per-lane offsets (tile offsets stay below 2^27 elements)
-        const uint32_t *in = a.in + (uint64_t)batch * a.in_stride + t.in_base;
-        if (!LAST) {
-            const uint32_t blog = a.L - a.Sp - LOGR;
-            // thread-constant column w; rows j = j0 + i*T.  The coset scale q^g of input index
-            // g = g0 + i*(T<<blog) advances by the constant pre_ratio = q^(T<<blog).
-            const uint32_t w = tid & (W - 1), j0 = tid >> LOGW;
-            const uint32_t o0 = (j0 << blog) + w;
-            uint32_t v[V];
-            if (a.flags & NTT_FIRST) {
-                // zero padding: in_base == b0 in the first pass, so b0 + o is the natural index.
-                // Branch-free (clamped address + select) so the 16 loads issue back to back.
-                const uint32_t *col = a.in + (uint64_t)batch * a.in_stride;
+    // ---- strided passes: the 16 global loads of a thread are rows j0 + i*(R/16) of column w --
+    // exactly the inputs of its radix-16 butterfly (pos = j0), so step 0 runs on them directly.
+    static SMI_HD void load_regs(const PassArgs &a, const TileId &t, uint32_t batch, uint32_t (&v)[V], uint32_t tid) {
+        const uint32_t blog = a.L - a.Sp - LOGR;
+        const uint32_t w = tid & (W - 1), j0 = tid >> LOGW;
+        const uint32_t o0 = (j0 << blog) + w;
+        if (a.flags & NTT_FIRST) {
+            // zero padding: in_base == b0 in the first pass, so b0 + o is the natural index.
+            // Branch-free (clamped address + select) so the 16 loads issue back to back.
+            const uint32_t *col = a.in + (uint64_t)batch * a.in_stride;
+#pragma unroll
+            for (int i = 0; i < V; i++) {
+                const uint32_t g = t.b0 + o0 + ((uint32_t)(i * (NT >> LOGW)) << blog);
+                const uint32_t x = col[g < a.n_in ? g : 0u];
+                v[i] = g < a.n_in ? x : 0u;
+            }
+            if (a.flags & NTT_PRE_SCALE) {
+                // coset scale q^g: g advances by the constant T<<blog between a thread's loads
+                uint32_t sc = two_level(a.S.lo, a.S.hi, a.S.h, t.b0 + o0, a.F);
+                const uint32_t rq = a.pre_ratio_m * a.F.pinv;
 #pragma unroll
                 for (int i = 0; i < V; i++) {
-                    const uint32_t g = t.b0 + o0 + ((uint32_t)(i * (NT >> LOGW)) << blog);
-                    const uint32_t x = col[g < a.n_in ? g : 0u];
-                    v[i] = g < a.n_in ? x : 0u;
+                    v[i] = mont_mul(v[i], sc, a.F);
+                    sc = mont_mul_c(sc, a.pre_ratio_m, rq, a.F);
                 }
-                if (a.flags & NTT_PRE_SCALE) {
-                    uint32_t sc = two_level(a.S.lo, a.S.hi, a.S.h, t.b0 + o0, a.F);
-                    const uint32_t rq = a.pre_ratio_m * a.F.pinv;
-#pragma unroll
-                    for (int i = 0; i < V; i++) {
-                        v[i] = mont_mul(v[i], sc, a.F);
-                        sc = mont_mul_c(sc, a.pre_ratio_m, rq, a.F);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < V; i++) v[i] = in[o0 + ((uint32_t)(i * (NT >> LOGW)) << blog)];
             }
-#pragma unroll
-            for (int i = 0; i < V; i++) tile[(j0 + i * (NT >> LOGW)) * WP + w] = v[i];
         } else {
-            const uint32_t arest_log = a.Sp - a.d0_log;
-            uint32_t v[V];
+            const uint32_t *in = a.in + (uint64_t)batch * a.in_stride + t.in_base;
 #pragma unroll
-            for (int i = 0; i < V; i++) {
-                const uint32_t idx = tid + i * NT;
-                const uint32_t j = idx & (R - 1), l = idx >> LOGR;
-                v[i] = in[(l << (arest_log + LOGR)) + j];
-            }
-#pragma unroll
-            for (int i = 0; i < V; i++) {
-                const uint32_t idx = tid + i * NT;
-                tile[(idx & (R - 1)) * WP + (idx >> LOGR)] = v[i];
-            }
+            for (int i = 0; i < V; i++) v[i] = in[o0 + ((uint32_t)(i * (NT >> LOGW)) << blog)];
         }
     }
 
-    // One radix-2^S step on sub-blocks of 2^MLOG points (MLOG = log2 M of this step).
+    // radix-16 step 0 on registers (strided passes); writes the tile to LDS
+    static SMI_HD void step0_regs(const PassArgs &a, uint32_t (&x)[V], uint32_t *tile, const Tw2 *tw, uint32_t tid) {
+        enum { SUB = LOGR - 4 };
+        const uint32_t w = tid & (W - 1), pos = tid >> LOGW;
+        dft_regs<4>(x, tw, LOGR - 4, a.F);
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) {
+            uint32_t v = x[brev<4>(kk)];
+            if (kk) v = shoup_mul(v, tw[(pos * kk) & (R - 1)], a.F.p);
+            tile[(pos + ((uint32_t)kk << SUB)) * WP + w] = v;
+        }
+    }
+
+    // ---- last pass: rows are contiguous in HBM; load coalesced along the row, transpose via LDS
+    static SMI_HD void load_lds(const PassArgs &a, const TileId &t, uint32_t batch, uint32_t *tile, uint32_t tid) {
+        const uint32_t *in = a.in + (uint64_t)batch * a.in_stride + t.in_base;
+        const uint32_t arest_log = a.Sp - a.d0_log;
+        uint32_t v[V];
+#pragma unroll
+        for (int i = 0; i < V; i++) {
+            const uint32_t idx = tid + i * NT;
+            const uint32_t j = idx & (R - 1), l = idx >> LOGR;
+            v[i] = in[(l << (arest_log + LOGR)) + j];
+        }
+#pragma unroll
+        for (int i = 0; i < V; i++) {
+            const uint32_t idx = tid + i * NT;
+            tile[(idx & (R - 1)) * WP + (idx >> LOGR)] = v[i];
+        }
+    }
+
+    // One radix-2^S step LDS -> LDS on sub-blocks of 2^MLOG points (never the last step).
     template <int S, int MLOG> static SMI_HD void step(const PassArgs &a, uint32_t *tile, const Tw2 *tw, uint32_t tid) {
         enum { r = 1 << S, SUB = MLOG - S, NB = (TILE / r) / NT };
 #pragma unroll
@@ -232,93 +264,80 @@ template <int LOGR, int LOGW, bool LAST> struct NttPass {
 #pragma unroll
             for (int kk = 0; kk < r; kk++) {
                 uint32_t v = x[brev<S>(kk)];
-                if (SUB > 0 && kk) {
-                    const Tw2 c = tw[((pos * kk) << (LOGR - MLOG)) & (R - 1)];
-                    v = mont_mul_c(v, c.w, c.q, a.F);
-                }
+                if (kk) v = shoup_mul(v, tw[((pos * kk) << (LOGR - MLOG)) & (R - 1)], a.F.p);
                 tile[(base + ((uint32_t)kk << SUB)) * WP + w] = v;
             }
         }
     }
-
-    // step I of the in-tile transform (I < St::n)
-    template <int I> static SMI_HD void step_i(const PassArgs &a, uint32_t *tile, const Tw2 *tw, uint32_t tid) {
-        if constexpr (I == 0) step<St::s0, LOGR>(a, tile, tw, tid);
-        else if constexpr (I == 1) step<St::s1, LOGR - St::s0>(a, tile, tw, tid);
-        else if constexpr (I == 2 && St::n == 3) step<St::s2, LOGR - St::s0 - St::s1>(a, tile, tw, tid);
+    static SMI_HD void step0_lds(const PassArgs &a, uint32_t *tile, const Tw2 *tw, uint32_t tid) { step<4, LOGR>(a, tile, tw, tid); }
+    // the middle step of a three-step tile (no-op for two-step tiles)
+    static SMI_HD void step_mid(const PassArgs &a, uint32_t *tile, const Tw2 *tw, uint32_t tid) {
+        if constexpr (St::n == 3) step<St::s1, LOGR - St::s0>(a, tile, tw, tid);
     }
 
-    // position in the line after all steps -> natural in-line frequency index
-    static SMI_HD uint32_t loc_to_k(uint32_t loc) {
-        if (St::n == 2) {
-            const uint32_t k0 = loc >> St::s1, k1 = loc & ((1u << St::s1) - 1u);
-            return k0 | (k1 << St::s0);
-        } else {
-            const uint32_t k0 = loc >> (St::s1 + St::s2);
-            const uint32_t k1 = (loc >> St::s2) & ((1u << St::s1) - 1u);
-            const uint32_t k2 = loc & ((1u << St::s2) - 1u);
-            return k0 | (k1 << St::s0) | (k2 << (St::s0 + St::s1));
-        }
+    // position of a last-step block (all digits but the last) -> its weight in the frequency index
+    static SMI_HD uint32_t blk_to_k(uint32_t blk) {
+        if (St::n == 2) return blk;                                  // k0
+        const uint32_t k0 = blk >> St::s1, k1 = blk & ((1u << St::s1) - 1u);
+        return k0 | (k1 << St::s0);
     }
 
-    // rest digits of a position (everything below the leading radix-16 digit) -> their weight in k
-    static SMI_HD uint32_t rest_to_k(uint32_t loc0) {
-        if (St::n == 2) return loc0;  // k1
-        const uint32_t k1 = loc0 >> St::s2, k2 = loc0 & ((1u << St::s2) - 1u);
-        return k1 | (k2 << St::s1);
-    }
-
-    static SMI_HD void store(const PassArgs &a, const TileId &t, uint32_t batch, const uint32_t *tile, uint32_t tid) {
+    // Last in-tile step (radix RL, no step twiddles) fused with the store: outputs leave from
+    // registers.  A butterfly's outputs are frequencies k = kbase + kk*(R/RL), kk < RL: an
+    // arithmetic progression, so inter-pass twiddles / output scales are running products.
+    static SMI_HD void last_step_store(const PassArgs &a, const TileId &t, uint32_t batch, const uint32_t *tile, const Tw2 *tw,
+                                       uint32_t tid) {
+        enum { NB = (TILE / RL) / NT, KSTEP_LOG = LOGR - SL };
         uint32_t *out = a.out + (uint64_t)batch * a.out_stride + t.out_base;
-        const uint32_t mlog = a.L - a.Sp;  // log2 m (sub-problem size of this pass)
-        // thread-constant column w; positions loc = loc0 + i*T have leading digit i, so the
-        // frequencies are k = i + 16*krest, i = 0..15.
-        const uint32_t w = tid & (W - 1), loc0 = tid >> LOGW;
-        const uint32_t krest = rest_to_k(loc0);
-        if (!LAST) {
-            const uint32_t blog = mlog - LOGR;
-            const uint32_t b = t.b0 + w;
-            const uint32_t o0 = ((krest << 4) << blog) + w;
-            if (a.ptab) {
-                // passes after the first: w_m^(k*b) from the (L2-resident) table of this pass,
-                // read with the same coalescing as the data
-                const Tw2 *tab = a.ptab + t.b0;
+        const uint32_t mlog = a.L - a.Sp, p = a.F.p;
 #pragma unroll
-                for (int i = 0; i < V; i++) {
-                    const uint32_t loc = loc0 + i * (NT >> LOGW);
-                    const uint32_t o = o0 + ((uint32_t)i << blog);
-                    const Tw2 c = tab[o];
-                    out[o] = mont_mul_c(tile[loc * WP + w], c.w, c.q, a.F);
+        for (int bi = 0; bi < NB; bi++) {
+            const uint32_t u = tid + bi * NT;
+            const uint32_t w = u & (W - 1), blk = u >> LOGW;
+            uint32_t x[RL];
+#pragma unroll
+            for (int q = 0; q < RL; q++) x[q] = tile[(blk * RL + q) * WP + w];
+            dft_regs<SL>(x, tw, LOGR - SL, a.F);
+            const uint32_t kbase = blk_to_k(blk);
+            if (!LAST) {
+                const uint32_t blog = mlog - LOGR;
+                const uint32_t o0 = (kbase << blog) + w;
+                if (a.ptab) {
+                    // passes after the first: w_m^(k*b) from this pass's (L2-resident) table, read
+                    // with the data's own coalescing
+                    const Tw2 *tab = a.ptab + t.b0;
+#pragma unroll
+                    for (int kk = 0; kk < RL; kk++) {
+                        const uint32_t o = o0 + ((uint32_t)kk << (KSTEP_LOG + blog));
+                        out[o] = lz_canon(shoup_mul(x[brev<SL>(kk)], tab[o], p), p);
+                    }
+                } else {
+                    // first pass (m = n: a table would double the traffic): w_m^(k*b) = g^k, g = w_m^b;
+                    // two lookups per butterfly, then a running product over kk
+                    const uint32_t b = t.b0 + w, sh = a.T.K - mlog;
+                    uint32_t cur = two_level(a.T.lo, a.T.hi, a.T.h, (b * kbase) << sh, a.F);
+                    const uint32_t gs = two_level(a.T.lo, a.T.hi, a.T.h, (b << KSTEP_LOG) << sh, a.F);  // g^(R/RL)
+                    const uint32_t gq = gs * a.F.pinv;
+#pragma unroll
+                    for (int kk = 0; kk < RL; kk++) {
+                        out[o0 + ((uint32_t)kk << (KSTEP_LOG + blog))] = mont_mul(x[brev<SL>(kk)], cur, a.F);
+                        cur = mont_mul_c(cur, gs, gq, a.F);
+                    }
                 }
             } else {
-                // first pass (m = n: a table would double the traffic): w_m^(k*b) = g^k with
-                // g = w_m^b; two lookups per thread, then a running product over consecutive k.
-                const uint32_t sh = a.T.K - mlog;
-                const uint32_t g = two_level(a.T.lo, a.T.hi, a.T.h, b << sh, a.F);
-                const uint32_t gq = g * a.F.pinv;
-                uint32_t cur = two_level(a.T.lo, a.T.hi, a.T.h, (b * (krest << 4)) << sh, a.F);
-#pragma unroll
-                for (int i = 0; i < V; i++) {
-                    const uint32_t loc = loc0 + i * (NT >> LOGW);
-                    const uint32_t v = mont_mul(tile[loc * WP + w], cur, a.F);
-                    cur = mont_mul_c(cur, g, gq, a.F);
-                    out[o0 + ((uint32_t)i << blog)] = v;
-                }
-            }
-        } else {
-            const uint32_t o0 = ((krest << 4) << a.Sp) + w;
-            uint32_t sc = 0;
-            if (a.flags & NTT_POST_SCALE) sc = two_level(a.S.lo, a.S.hi, a.S.h, (uint32_t)t.out_base + o0, a.F);
-            const uint32_t rq = a.post_ratio_m * a.F.pinv;
-#pragma unroll
-            for (int i = 0; i < V; i++) {
-                const uint32_t loc = loc0 + i * (NT >> LOGW);
-                uint32_t v = tile[loc * WP + w];
+                const uint32_t o0 = (kbase << a.Sp) + w;
                 if (a.flags & NTT_POST_SCALE) {
-                    v = mont_mul(v, sc, a.F);
-                    sc = mont_mul_c(sc, a.post_ratio_m, rq, a.F);
+                    uint32_t sc = two_level(a.S.lo, a.S.hi, a.S.h, (uint32_t)t.out_base + o0, a.F);
+                    const uint32_t rq = a.post_ratio_m * a.F.pinv;
+#pragma unroll
+                    for (int kk = 0; kk < RL; kk++) {
+                        out[o0 + ((uint32_t)kk << (KSTEP_LOG + a.Sp))] = mont_mul(x[brev<SL>(kk)], sc, a.F);
+                        sc = mont_mul_c(sc, a.post_ratio_m, rq, a.F);
+                    }
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < RL; kk++) out[o0 + ((uint32_t)kk << (KSTEP_LOG + a.Sp))] = lz_canon(x[brev<SL>(kk)], p);
                 }
-                out[o0 + ((uint32_t)i << a.Sp)] = v;
             }
         }
     }

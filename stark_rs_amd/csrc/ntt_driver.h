@@ -56,7 +56,7 @@ template <class Launcher> inline void ntt_run(Launcher &ln, const NttRequest &rq
         {   // steps of the running-product scales (see NttPass::load / store)
             const uint32_t logw = (uint32_t)pl.logw[p], blog = rq.L - consumed - (uint32_t)pl.logr[p];
             const uint64_t pre_step = (uint64_t)((1u << (pl.logr[p] + pl.logw[p] - 4)) >> logw) << blog;
-            const uint32_t pr = host_powmod(rq.q_plain, pre_step, rq.F.p), po = host_powmod(rq.q_plain, 1ull << consumed, rq.F.p);
+            const uint32_t pr = host_powmod(rq.q_plain, pre_step, rq.F.p), po = host_powmod(rq.q_plain, 1ull << (consumed + (uint32_t)pl.logr[p] - (uint32_t)ntt_last_step_log(pl.logr[p])), rq.F.p);
             a.pre_ratio_m = (uint32_t)(((uint64_t)pr << 32) % rq.F.p);
             a.post_ratio_m = (uint32_t)(((uint64_t)po << 32) % rq.F.p);
         }

@@ -89,6 +89,9 @@ inline NttPlan ntt_make_plan(uint32_t L) {
     return pl;
 }
 
+// log2 of the radix of the last in-tile step for a digit of logr bits (Steps<logr> in ntt_core.h)
+inline int ntt_last_step_log(int logr) { return logr == 6 ? 2 : logr == 7 ? 3 : logr == 8 ? 4 : logr == 9 ? 2 : 3; }
+
 // Geometric table entry (Montgomery form): c * q^(i*stride); q_m, c_m in Montgomery form.
 SMI_HD uint32_t geom_entry(uint32_t c_m, uint32_t q_m, uint64_t i, uint64_t stride, const Fp &F) {
     return mont_mul(c_m, mont_pow(q_m, i * stride, F), F);

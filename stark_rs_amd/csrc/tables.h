@@ -8,7 +8,7 @@ struct GeomSpec {
     uint32_t c_m, q_m;  // Montgomery form
     uint64_t stride;
     uint32_t count;
-    uint32_t pair;      // 1: write Tw2 entries (value, value * p^-1 mod 2^32)
+    uint32_t pair;      // 1: write Tw2 entries (plain value, Shoup quotient floor(value * 2^32 / p))
 };
 
 struct FieldSetup {
@@ -18,9 +18,10 @@ struct FieldSetup {
     uint32_t wmax[2];    // primitive 2^K-th root: [0] forward, [1] inverse (plain form)
 };
 
-// Returns false when p is unusable (even, >= 2^31, two-adicity < 12, or g not of full 2-power order).
+// Returns false when p is unusable (even, >= 2^30 -- the lazy butterflies need 4p < 2^32 --,
+// two-adicity < 12, or g not of full 2-power order).
 inline bool field_setup(uint64_t p64, uint64_t g64, FieldSetup *fs) {
-    if (p64 < 3 || p64 >= (1ull << 31) || (p64 & 1) == 0 || g64 == 0 || g64 >= p64) return false;
+    if (p64 < 3 || p64 >= (1ull << 30) || (p64 & 1) == 0 || g64 == 0 || g64 >= p64) return false;
     const uint32_t p = (uint32_t)p64, g = (uint32_t)g64;
     uint32_t two_adicity = 0;
     while (((p - 1) >> two_adicity) % 2 == 0) two_adicity++;
@@ -56,10 +57,16 @@ inline void scale_table_specs(const Fp &F, uint32_t c_plain, uint32_t q_plain, u
     specs[1] = GeomSpec{c_m, q_m, 1ull << h, 1u << (L - h), 0};
 }
 
+// Montgomery-form value -> plain value + Shoup quotient (64-bit divide: table generation only)
+SMI_HD Tw2 tw2_from_mont(uint32_t v_m, const Fp &F) {
+    const uint32_t w = from_mont(v_m, F);
+    return Tw2{w, (uint32_t)(((uint64_t)w << 32) / F.p)};
+}
+
 // Inter-pass twiddle table of one pass: entry [k*B + b] = w_m^(k*b), m = 2^mlog = R*B (Tw2 pairs).
 SMI_HD Tw2 pass_table_entry(uint32_t idx, uint32_t mlog, uint32_t logr, const NttTables &T, const Fp &F) {
     const uint32_t blog = mlog - logr, k = idx >> blog, b = idx & ((1u << blog) - 1u);
     const uint32_t e = (k * b) << (T.K - mlog);
     const uint32_t v = e ? two_level(T.lo, T.hi, T.h, e, F) : F.r1;
-    return Tw2{v, v * F.pinv};
+    return tw2_from_mont(v, F);
 }

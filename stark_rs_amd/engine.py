@@ -12,7 +12,7 @@ from . import _lib
 from ._lib import FriCfg, StarkMiError, check, vp
 
 P_REF, G_REF = 998244353, 3          # reference field (src/ff.rs:191-197)
-P2, G2 = 2013265921, 31              # 15*2^27+1: domains above 2^23
+P2, G2 = 469762049, 3              # 7*2^26+1: domains above 2^23; p < 2^30 keeps 4p < 2^32
 
 _default = {}
 

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 P, G = 998244353, 3
-P2, G2 = 2013265921, 31
+P2, G2 = 469762049, 3
 u32p = C.POINTER(C.c_uint32)
 
 

@@ -13,7 +13,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-P2, G2 = 2013265921, 31
+P2, G2 = 469762049, 3
 u32p = C.POINTER(C.c_uint32)
 
 

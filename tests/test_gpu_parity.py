@@ -6,7 +6,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 P, G = 998244353, 3
-P2, G2 = 2013265921, 31
+P2, G2 = 469762049, 3
 
 
 @pytest.fixture(scope="module")

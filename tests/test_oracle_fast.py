@@ -54,10 +54,10 @@ def test_fast_coset_ntt_equals_eval_domain(oracle, logd, logN, offset):
 
 
 def test_fast_paths_second_prime(oracle):
-    """P2 = 15*2^27+1: the oracle's arithmetic is p-generic (ff.rs:138-189)."""
+    """P2 = 7*2^26+1: the oracle's arithmetic is p-generic (ff.rs:138-189)."""
     o = oracle
     p, g = o.P2, o.G2
-    assert o.ff_exp(g, (p - 1) // 2, p) == p - 1            # 31 is a non-residue -> generator check
+    assert o.ff_exp(g, (p - 1) // 2, p) == p - 1            # g is a non-residue -> generator check
     n, N = 64, 512
     w, W = o.ff_prim_nth_root_g(n, p, g), o.ff_prim_nth_root_g(N, p, g)
     assert o.ff_exp(w, n // 2, p) == p - 1
