@@ -34,8 +34,13 @@ template <int LOGR, int LOGW, bool LAST> void emu_pass(const PassArgs &a, uint32
             for (uint32_t tid = 0; tid < NT; tid++) NP::load_tw(a, tw.data(), tid);
             if (!LAST) {
                 std::vector<std::array<uint32_t, 16>> regs(NT);   // per-thread registers live across the barrier
-                for (uint32_t tid = 0; tid < NT; tid++) NP::load_regs(a, t, b, reinterpret_cast<uint32_t(&)[16]>(regs[tid]), tid);
-                for (uint32_t tid = 0; tid < NT; tid++) NP::step0_regs(a, reinterpret_cast<uint32_t(&)[16]>(regs[tid]), tile.data(), tw.data(), tid);
+#define ZCASE(Z)                                                                                                           \
+    case Z:                                                                                                                \
+        for (uint32_t tid = 0; tid < NT; tid++) NP::template load_regs<Z>(a, t, b, reinterpret_cast<uint32_t(&)[16]>(regs[tid]), tid); \
+        for (uint32_t tid = 0; tid < NT; tid++) NP::template step0_regs<Z>(a, reinterpret_cast<uint32_t(&)[16]>(regs[tid]), tile.data(), tw.data(), tid); \
+        break;
+                switch (a.zlog) { ZCASE(0) ZCASE(1) ZCASE(2) ZCASE(3) ZCASE(4) }
+#undef ZCASE
             } else {
                 for (uint32_t tid = 0; tid < NT; tid++) NP::load_lds(a, t, b, tile.data(), tid);
                 for (uint32_t tid = 0; tid < NT; tid++) NP::step0_lds(a, tile.data(), tw.data(), tid);

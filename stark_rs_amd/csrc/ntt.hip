@@ -18,9 +18,16 @@ __global__ __launch_bounds__(1 << (LOGR + LOGW - 4)) void ntt_pass_kernel(const 
     NP::load_tw(a, tw, tid);
     if (!LAST) {
         uint32_t v[NP::V];
-        NP::load_regs(a, t, batch, v, tid);
-        __syncthreads();                       // twiddle table staged
-        NP::step0_regs(a, v, tile, tw, tid);
+        // zero-padded first passes (an LDE's blowup) skip the loads and the degenerate butterfly
+        // stages of the padding; zlog is wave-uniform
+#define ZCASE(Z)                                       \
+    case Z:                                            \
+        NP::template load_regs<Z>(a, t, batch, v, tid);  \
+        __syncthreads(); /* twiddle table staged */    \
+        NP::template step0_regs<Z>(a, v, tile, tw, tid); \
+        break;
+        switch (a.zlog) { ZCASE(2) ZCASE(3) ZCASE(4) default: ZCASE(0) }
+#undef ZCASE
     } else {
         NP::load_lds(a, t, batch, tile, tid);
         __syncthreads();

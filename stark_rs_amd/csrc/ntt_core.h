@@ -70,6 +70,8 @@ struct PassArgs {
     const Tw2 *ptab;        // inter-pass twiddles w_m^(k*b) at [k*B + b] for passes after the first (else null)
     uint32_t pre_ratio_m;   // q^(T*B): step of the input coset scale between a thread's loads (Montgomery)
     uint32_t post_ratio_m;  // q^((R/r_last) << Sp): step of the output scale between a thread's stores (Montgomery)
+    uint32_t post_bi_ratio_m;  // q^(r_last << Sp): step of the output scale between a thread's butterflies
+    uint32_t zlog;          // first pass: inputs with top digit >= 16 >> zlog are zero padding (0..4)
 };
 
 // digit structure of the in-tile transform; s0 = 4 everywhere, so the 16 values a thread loads in
@@ -112,7 +114,9 @@ SMI_HD uint32_t lz_canon(uint32_t a, uint32_t p) { return umin32(a, a - p); }  /
 
 // S-stage radix-2 DIF on 2^S registers, lazy; x[brev(k)] = X_k on return.  cw = w_R^j table in
 // LDS, croot_shift = LOGR - S so that w_r^j = cw[j << croot_shift].
-template <int S> SMI_HD void dft_regs(uint32_t (&x)[1 << S], const Tw2 *cw, int croot_shift, const Fp &F) {
+// Z: in the first Z stages the upper input of every butterfly is known to be zero (zero-padded
+// transform), so the butterfly degenerates to copy + twiddle.
+template <int S, int Z = 0> SMI_HD void dft_regs(uint32_t (&x)[1 << S], const Tw2 *cw, int croot_shift, const Fp &F) {
     const uint32_t p2 = 2u * F.p;
 #pragma unroll
     for (int s = 0; s < S; s++) {
@@ -121,10 +125,14 @@ template <int S> SMI_HD void dft_regs(uint32_t (&x)[1 << S], const Tw2 *cw, int 
         for (int i = 0; i < (1 << S); i++) {
             if (i & half) continue;
             const int j = i | half;
+            const int e = (i & (half - 1)) << s;    // w_{2half}^pos = w_r^(pos << s)
+            if (s < Z) {
+                x[j] = e ? shoup_mul(x[i], cw[e << croot_shift], F.p) : x[i];
+                continue;
+            }
             const uint32_t u = x[i], v = x[j];
             x[i] = lz_add(u, v, p2);
             const uint32_t d = u - v + p2;          // (0, 4p)
-            const int e = (i & (half - 1)) << s;    // w_{2half}^pos = w_r^(pos << s)
             x[j] = e ? shoup_mul(d, cw[e << croot_shift], F.p) : lz_fold(d, p2);
         }
     }
@@ -186,16 +194,18 @@ template <int LOGR, int LOGW, bool LAST> struct NttPass {
 
     // ---- strided passes: the 16 global loads of a thread are rows j0 + i*(R/16) of column w --
     // exactly the inputs of its radix-16 butterfly (pos = j0), so step 0 runs on them directly.
-    static SMI_HD void load_regs(const PassArgs &a, const TileId &t, uint32_t batch, uint32_t (&v)[V], uint32_t tid) {
+    // Z: rows i >= 16 >> Z are zero padding and are neither loaded nor scaled.
+    template <int Z> static SMI_HD void load_regs(const PassArgs &a, const TileId &t, uint32_t batch, uint32_t (&v)[V], uint32_t tid) {
         const uint32_t blog = a.L - a.Sp - LOGR;
         const uint32_t w = tid & (W - 1), j0 = tid >> LOGW;
         const uint32_t o0 = (j0 << blog) + w;
         if (a.flags & NTT_FIRST) {
             // zero padding: in_base == b0 in the first pass, so b0 + o is the natural index.
-            // Branch-free (clamped address + select) so the 16 loads issue back to back.
+            // Branch-free (clamped address + select) so the loads issue back to back.
             const uint32_t *col = a.in + (uint64_t)batch * a.in_stride;
 #pragma unroll
             for (int i = 0; i < V; i++) {
+                if (i >= (V >> Z)) { v[i] = 0u; continue; }
                 const uint32_t g = t.b0 + o0 + ((uint32_t)(i * (NT >> LOGW)) << blog);
                 const uint32_t x = col[g < a.n_in ? g : 0u];
                 v[i] = g < a.n_in ? x : 0u;
@@ -205,7 +215,7 @@ template <int LOGR, int LOGW, bool LAST> struct NttPass {
                 uint32_t sc = two_level(a.S.lo, a.S.hi, a.S.h, t.b0 + o0, a.F);
                 const uint32_t rq = a.pre_ratio_m * a.F.pinv;
 #pragma unroll
-                for (int i = 0; i < V; i++) {
+                for (int i = 0; i < (V >> Z); i++) {
                     v[i] = mont_mul(v[i], sc, a.F);
                     sc = mont_mul_c(sc, a.pre_ratio_m, rq, a.F);
                 }
@@ -218,10 +228,10 @@ template <int LOGR, int LOGW, bool LAST> struct NttPass {
     }
 
     // radix-16 step 0 on registers (strided passes); writes the tile to LDS
-    static SMI_HD void step0_regs(const PassArgs &a, uint32_t (&x)[V], uint32_t *tile, const Tw2 *tw, uint32_t tid) {
+    template <int Z> static SMI_HD void step0_regs(const PassArgs &a, uint32_t (&x)[V], uint32_t *tile, const Tw2 *tw, uint32_t tid) {
         enum { SUB = LOGR - 4 };
         const uint32_t w = tid & (W - 1), pos = tid >> LOGW;
-        dft_regs<4>(x, tw, LOGR - 4, a.F);
+        dft_regs<4, Z>(x, tw, LOGR - 4, a.F);
 #pragma unroll
         for (int kk = 0; kk < 16; kk++) {
             uint32_t v = x[brev<4>(kk)];
@@ -290,6 +300,26 @@ template <int LOGR, int LOGW, bool LAST> struct NttPass {
         enum { NB = (TILE / RL) / NT, KSTEP_LOG = LOGR - SL };
         uint32_t *out = a.out + (uint64_t)batch * a.out_stride + t.out_base;
         const uint32_t mlog = a.L - a.Sp, p = a.F.p;
+        // Butterfly bi of a thread has kbase = kbase_0 + bi * RL (its block index advances by R/16,
+        // i.e. k_0 by RL), so the per-butterfly bases are running products as well: three table
+        // lookups per thread whatever NB is.
+        uint32_t base_run = 0, gs = 0, gq = 0, gbi = 0, gbq = 0;   // first pass: g^kbase, g^(R/RL), g^RL
+        uint32_t sc_run = 0, rq = 0, rbq = 0;                        // last pass: scale(kn_base) and ratios
+        if (!LAST && !a.ptab) {
+            const uint32_t b = t.b0 + (tid & (W - 1)), sh = a.T.K - mlog;
+            base_run = two_level(a.T.lo, a.T.hi, a.T.h, (b * blk_to_k(tid >> LOGW)) << sh, a.F);
+            gs = two_level(a.T.lo, a.T.hi, a.T.h, (b << KSTEP_LOG) << sh, a.F);
+            gq = gs * a.F.pinv;
+            if (NB > 1) {
+                gbi = two_level(a.T.lo, a.T.hi, a.T.h, (b << SL) << sh, a.F);
+                gbq = gbi * a.F.pinv;
+            }
+        }
+        if (LAST && (a.flags & NTT_POST_SCALE)) {
+            sc_run = two_level(a.S.lo, a.S.hi, a.S.h, (uint32_t)t.out_base + (blk_to_k(tid >> LOGW) << a.Sp) + (tid & (W - 1)), a.F);
+            rq = a.post_ratio_m * a.F.pinv;
+            rbq = a.post_bi_ratio_m * a.F.pinv;
+        }
 #pragma unroll
         for (int bi = 0; bi < NB; bi++) {
             const uint32_t u = tid + bi * NT;
@@ -313,26 +343,24 @@ template <int LOGR, int LOGW, bool LAST> struct NttPass {
                     }
                 } else {
                     // first pass (m = n: a table would double the traffic): w_m^(k*b) = g^k, g = w_m^b;
-                    // two lookups per butterfly, then a running product over kk
-                    const uint32_t b = t.b0 + w, sh = a.T.K - mlog;
-                    uint32_t cur = two_level(a.T.lo, a.T.hi, a.T.h, (b * kbase) << sh, a.F);
-                    const uint32_t gs = two_level(a.T.lo, a.T.hi, a.T.h, (b << KSTEP_LOG) << sh, a.F);  // g^(R/RL)
-                    const uint32_t gq = gs * a.F.pinv;
+                    // running products over kk (and over the thread's butterflies, see above)
+                    uint32_t cur = base_run;
+                    if (bi + 1 < NB) base_run = mont_mul_c(base_run, gbi, gbq, a.F);
 #pragma unroll
                     for (int kk = 0; kk < RL; kk++) {
                         out[o0 + ((uint32_t)kk << (KSTEP_LOG + blog))] = mont_mul(x[brev<SL>(kk)], cur, a.F);
-                        cur = mont_mul_c(cur, gs, gq, a.F);
+                        if (kk + 1 < RL) cur = mont_mul_c(cur, gs, gq, a.F);
                     }
                 }
             } else {
                 const uint32_t o0 = (kbase << a.Sp) + w;
                 if (a.flags & NTT_POST_SCALE) {
-                    uint32_t sc = two_level(a.S.lo, a.S.hi, a.S.h, (uint32_t)t.out_base + o0, a.F);
-                    const uint32_t rq = a.post_ratio_m * a.F.pinv;
+                    uint32_t sc = sc_run;
+                    if (bi + 1 < NB) sc_run = mont_mul_c(sc_run, a.post_bi_ratio_m, rbq, a.F);
 #pragma unroll
                     for (int kk = 0; kk < RL; kk++) {
                         out[o0 + ((uint32_t)kk << (KSTEP_LOG + a.Sp))] = mont_mul(x[brev<SL>(kk)], sc, a.F);
-                        sc = mont_mul_c(sc, a.post_ratio_m, rq, a.F);
+                        if (kk + 1 < RL) sc = mont_mul_c(sc, a.post_ratio_m, rq, a.F);
                     }
                 } else {
 #pragma unroll

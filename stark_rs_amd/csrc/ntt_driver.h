@@ -59,6 +59,12 @@ template <class Launcher> inline void ntt_run(Launcher &ln, const NttRequest &rq
             const uint32_t pr = host_powmod(rq.q_plain, pre_step, rq.F.p), po = host_powmod(rq.q_plain, 1ull << (consumed + (uint32_t)pl.logr[p] - (uint32_t)ntt_last_step_log(pl.logr[p])), rq.F.p);
             a.pre_ratio_m = (uint32_t)(((uint64_t)pr << 32) % rq.F.p);
             a.post_ratio_m = (uint32_t)(((uint64_t)po << 32) % rq.F.p);
+            const uint32_t pb = host_powmod(rq.q_plain, 1ull << (consumed + (uint32_t)ntt_last_step_log(pl.logr[p])), rq.F.p);
+            a.post_bi_ratio_m = (uint32_t)(((uint64_t)pb << 32) % rq.F.p);
+            // zero padding seen by the first pass: rows j >= R * n_in / n hold no input
+            uint32_t z = 0;
+            while (first && z < 4 && ((uint64_t)rq.n_in << (z + 1)) <= n) z++;
+            a.zlog = z;
         }
         ln.pass(pl.logr[p], pl.logw[p], last, a, rq.batch);
         consumed += (uint32_t)pl.logr[p];
