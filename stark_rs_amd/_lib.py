@@ -68,6 +68,13 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise StarkMiError(-100, f"{LIB_PATH} is missing: run `make -C stark_rs_amd` (hipcc, gfx950). "
                                  "There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 (same SONAME as the
+    # system one).  If torch is loaded after us the process ends up with two runtimes and torch
+    # then sees no GPU; importing it first makes our DT_NEEDED resolve to the copy it loaded.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     sz = C.c_size_t
     i32 = C.c_int
