@@ -80,7 +80,7 @@ inline NttPlan ntt_make_plan(uint32_t L) {
         const int limit = last ? pl.logr[0] : (int)L - consumed;
         int best = -1;
         for (int lw = 2; lw <= 6; lw++)
-            if (ntt_shape_ok(pl.logr[i], lw) && lw <= limit && pl.logr[i] + lw <= (last ? 13 : 14) && lw <= (last ? 4 : 5)) best = lw;
+            if (ntt_shape_ok(pl.logr[i], lw) && lw <= limit && pl.logr[i] + lw <= (last ? 13 : 14) && lw <= 5) best = lw;
         if (best < 0)
             for (int lw = 6; lw >= 2; lw--)
                 if (ntt_shape_ok(pl.logr[i], lw) && lw <= limit) best = lw;
