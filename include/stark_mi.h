@@ -113,6 +113,9 @@ int smi_coset_ntt(smi_ctx *ctx, const uint64_t *coeffs, size_t n_coeffs, uint64_
                   uint64_t offset);
 /* Polynomial::scale (src/univariate/mod.rs:99-113): out[i] = coeffs[i] * factor^i. */
 int smi_poly_scale(smi_ctx *ctx, const uint64_t *coeffs, size_t n, uint64_t factor, uint64_t *out);
+/* Polynomial::mul (src/univariate/mul.rs:6-29) by NTT: out gets na+nb-1 coefficients (*n_out),
+ * or *n_out = 0 when either operand is the zero polynomial, as the reference returns `vec![]`. */
+int smi_poly_mul(smi_ctx *ctx, const uint64_t *a, size_t na, const uint64_t *b, size_t nb, uint64_t *out, size_t *n_out);
 /* Checks in O(n) whether domain[k] == domain[0]*omega_n^k (the fast-path contract of
  * interpolate_domain / eval_domain); returns SMI_OK and *offset = domain[0], or
  * SMI_ERR_NOT_GEOMETRIC. */

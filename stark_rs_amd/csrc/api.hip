@@ -423,6 +423,49 @@ int smi_poly_scale(smi_ctx *ctx, const uint64_t *coeffs, size_t n, uint64_t fact
     return check_flag(ctx);
 }
 
+// Polynomial::mul (src/univariate/mul.rs:6-29) through two forward transforms, a pointwise
+// product and one inverse transform (the reference's schoolbook loop is O(n^2)).
+__global__ void pointwise_mul_kernel(uint32_t *a, const uint32_t *b, size_t n, Fp F) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += step) a[i] = mont_mul(to_mont(a[i], F), b[i], F);
+}
+int smi_poly_mul(smi_ctx *ctx, const uint64_t *a, size_t na, const uint64_t *b, size_t nb, uint64_t *out, size_t *n_out) {
+    if (!ctx || !n_out || (na && !a) || (nb && !b)) return SMI_ERR_BAD_ARG;
+    // zero operands give the empty polynomial, exactly like mul.rs:7-12 (is_zero = deg == -1)
+    bool za = true, zb = true;
+    for (size_t i = 0; i < na; i++) za = za && a[i] == 0;
+    for (size_t i = 0; i < nb; i++) zb = zb && b[i] == 0;
+    if (za || zb) { *n_out = 0; return SMI_OK; }
+    if (!out) return SMI_ERR_BAD_ARG;
+    const size_t n = na + nb - 1;   // coeffs.len() of the reference's result
+    uint32_t L = 0;
+    while (((size_t)1 << L) < n) L++;
+    if (L > ctx->fs.K) return smi_fail(ctx, SMI_ERR_ROOT_TOO_LARGE, "product too long for this modulus");
+    const size_t N = (size_t)1 << L;
+    void *stage, *d_a, *d_b, *d_fa;
+    SMI_TRY(ctx_tmp(ctx, 0, (N > na + nb ? N : na + nb) * 8, &stage));
+    SMI_TRY(ctx_tmp(ctx, 1, (na + nb) * 4, &d_a));
+    SMI_TRY(ctx_tmp(ctx, 2, N * 4, &d_fa));
+    SMI_TRY(ctx_tmp(ctx, 3, N * 4, &d_b));
+    uint32_t *ua = (uint32_t *)d_a, *ub = ua + na, *fa = (uint32_t *)d_fa, *fb = (uint32_t *)d_b;
+    HIP_TRY(ctx, hipMemcpyAsync(stage, a, na * 8, hipMemcpyHostToDevice, ctx->stream));
+    SMI_TRY(launch_narrow(ctx, (const uint64_t *)stage, ua, na, 0));
+    HIP_TRY(ctx, hipMemcpyAsync((uint64_t *)stage + na, b, nb * 8, hipMemcpyHostToDevice, ctx->stream));
+    SMI_TRY(launch_narrow(ctx, (const uint64_t *)stage + na, ub, nb, 0));
+    SMI_TRY(dev_ntt(ctx, ua, fa, L, na, 1, na, N, 0, 1, 1));
+    SMI_TRY(dev_ntt(ctx, ub, fb, L, nb, 1, nb, N, 0, 1, 1));
+    size_t grid = (N + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    pointwise_mul_kernel<<<(uint32_t)grid, 256, 0, ctx->stream>>>(fa, fb, N, ctx->fs.F);
+    HIP_TRY(ctx, hipGetLastError());
+    SMI_TRY(dev_ntt(ctx, fa, fa, L, N, 1, N, N, 1, 1, 1));
+    SMI_TRY(launch_widen(ctx, fa, (uint64_t *)stage, n));
+    HIP_TRY(ctx, hipMemcpyAsync(out, stage, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    *n_out = n;
+    return check_flag(ctx);
+}
+
 int smi_lde(smi_ctx *ctx, const uint64_t *cols, uint32_t n_cols, uint32_t log_n, uint32_t log_blowup, uint64_t trace_offset,
             uint64_t lde_offset, uint64_t *out) {
     if (!ctx || !cols || !out || !n_cols) return SMI_ERR_BAD_ARG;

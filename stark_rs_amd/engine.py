@@ -112,6 +112,14 @@ class Engine:
         self._ck(self.L.smi_poly_scale(self.h, c.ctypes.data, len(c), factor, out.ctypes.data))
         return out
 
+    def poly_mul(self, a, b):
+        """Polynomial::mul (mul.rs:6-29) by NTT."""
+        a, b = _u64(a), _u64(b)
+        out = np.empty(max(len(a) + len(b), 1), dtype=np.uint64)
+        n = C.c_size_t()
+        self._ck(self.L.smi_poly_mul(self.h, a.ctypes.data, len(a), b.ctypes.data, len(b), out.ctypes.data, C.byref(n)))
+        return out[:n.value].copy()
+
     def domain_is_geometric(self, domain):
         d = _u64(domain)
         off = C.c_uint64()

@@ -193,6 +193,13 @@ class Polynomial:
         out = self.field.engine().poly_scale(_vals(self.coeffs), factor.value % self.field.p)
         return Polynomial([FieldElement(int(v), self.field) for v in out], self.field)
 
+    def __mul__(self, o):
+        """Polynomial::mul (mul.rs:6-29), NTT-based on the device."""
+        out = self.field.engine().poly_mul(_vals(self.coeffs), _vals(o.coeffs))
+        return Polynomial([FieldElement(int(v), self.field) for v in out], self.field)
+
+    mul = staticmethod(lambda lhs, rhs: lhs * rhs)
+
     @staticmethod
     def interpolate_domain(domain, values):
         """interpolate.rs:6-44 for a geometric domain offset*omega_n^k (the fast-path contract)."""

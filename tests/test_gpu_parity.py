@@ -116,6 +116,19 @@ def test_poly_scale(eng, oracle):
     assert list(eng.poly_scale(c, 12345)) == o.poly_scale(c, 12345)
 
 
+def test_poly_mul_equals_schoolbook_oracle(eng, oracle):
+    """Polynomial::mul (mul.rs:6-29) -- the oracle's O(n^2) restatement, incl. the reference KATs."""
+    o = oracle
+    assert list(eng.poly_mul([1, 1], [1, 1])) == [1, 2, 1]                       # test_mul_linear
+    assert list(eng.poly_mul([1, 0, 2], [3, 0, 4])) == [3, 0, 10, 0, 8]          # test_mul_sparse
+    assert list(eng.poly_mul([2], [1, 0, 1])) == [2, 0, 2]                       # test_mul_different_degrees
+    assert list(eng.poly_mul([P - 1], [2])) == [(2 * (P - 1)) % P]               # test_mul_overflow
+    assert len(eng.poly_mul([2, 3], [])) == 0 and len(eng.poly_mul([0, 0], [2, 3])) == 0   # test_mul_zero
+    for na, nb in ((5, 9), (100, 157), (700, 325), (1024, 1024)):
+        a, b = _vals(o, na, na), _vals(o, nb, nb)
+        assert list(eng.poly_mul(a, b)) == o.poly_mul(a, b)
+
+
 def test_lde_cfg3_small(eng, oracle):
     """4 columns, blowup 8: interpolate on the subgroup, evaluate on the coset g*<W>."""
     o = oracle
