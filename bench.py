@@ -231,6 +231,30 @@ def main():
           except Exception as e:  # an extra: never lose the headline line over it
             result["four_step_error"] = str(e)
 
+        # ---- one 2^25-point codeword sharded over the N GPUs: Fri::commit with per-rank Merkle
+        # subtrees, all-gathered sub-roots and the pairwise fold exchange
+        if distributed:
+          try:
+            from stark_rs_amd.sharded import HipShardBackend, ShardedFriCommit
+            logN = LOG_ROWS + LOG_BLOWUP
+            blk = (1 << logN) // world
+            be = HipShardBackend(eng)
+            block = be.tensor(splitmix64(9 + rank, blk) % np.uint64(p))
+            fc = ShardedFriCommit(be, p, eng.prim_nth_root(1 << logN), s.G2, 1 << logN, 1 << LOG_BLOWUP, N_TESTS, rank, world)
+            fc.commit(block)
+            torch.cuda.synchronize()
+            barrier()
+            t1 = time.perf_counter()
+            fc.commit(block)
+            torch.cuda.synchronize()
+            barrier()
+            dt = time.perf_counter() - t1
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            result["sharded_fri_commit_2p25_ms"] = 1e3 * float(tt.item())
+          except Exception as e:
+            result["sharded_fri_commit_error"] = str(e)
+
         if rank == 0 and world == 1:
             result["cpu_baseline"] = cpu_baseline()
 

@@ -209,6 +209,11 @@ int smi_dev_merkle_from_digests(smi_ctx *ctx, size_t n, uint8_t *d_nodes);
 /* Fri::fold_codeword with alpha read from device memory (*d_alpha: one unreduced u64). */
 int smi_dev_fri_fold(smi_ctx *ctx, const uint32_t *d_in, size_t len, const uint64_t *d_alpha, uint64_t offset,
                      uint64_t omega, uint32_t *d_out);
+/* The same fold for one shard of a codeword distributed over several GPUs: `count`
+ * outputs starting at global output index index0, d_lo[k] = c[index0+k], d_hi[k] =
+ * c[index0+k+full_len/2] (the second operand arrives from the partner GPU). */
+int smi_dev_fri_fold_shard(smi_ctx *ctx, const uint32_t *d_lo, const uint32_t *d_hi, size_t count, size_t index0,
+                           size_t full_len, const uint64_t *d_alpha, uint64_t offset, uint64_t omega, uint32_t *d_out);
 /* Fri::commit + the query phase of Fri::prove over a device codeword.  Roots, alphas and
  * the serialized proof are produced without a host round trip per round: Fiat-Shamir and
  * index sampling run in single-lane device kernels. */

@@ -129,6 +129,7 @@ def lib():
         "smi_dev_merkle_build": (i32, [vp, vp, sz, vp]),
         "smi_dev_merkle_from_digests": (i32, [vp, sz, vp]),
         "smi_dev_fri_fold": (i32, [vp, vp, sz, vp, C.c_uint64, C.c_uint64, vp]),
+        "smi_dev_fri_fold_shard": (i32, [vp, vp, vp, sz, sz, sz, vp, C.c_uint64, C.c_uint64, vp]),
         "smi_dev_fri_prove": (i32, [vp, C.POINTER(FriCfg), vp, sz, C.POINTER(vp), C.POINTER(sz), vp, C.POINTER(vp)]),
         "smi_dev_combine_columns": (i32, [vp, vp, C.c_uint32, sz, sz, vp, vp]),
         "smi_dev_stark_prove": (i32, [vp, C.POINTER(StarkCfg), vp, vp, C.POINTER(vp), C.POINTER(sz), vp, vp]),

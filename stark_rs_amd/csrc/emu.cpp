@@ -147,3 +147,23 @@ extern "C" void emu_hash_bytes(const uint8_t *msg, size_t len, uint8_t *out) {
     hashc::hash_bytes(msg, len, d);
     memcpy(out, d, 32);
 }
+
+// ---- FRI fold arithmetic (fri_core.h) ---------------------------------------------------
+#include "fri_core.h"
+extern "C" int emu_fold_shard(uint64_t p, uint64_t g, const uint32_t *lo, const uint32_t *hi, uint32_t count, uint32_t i0,
+                              uint32_t full_len, uint64_t alpha, uint64_t offset, uint64_t omega, uint32_t *out) {
+    FieldSetup fs;
+    if (!field_setup(p, g, &fs)) return -1;
+    const Fp &F = fs.F;
+    const uint32_t pp = F.p;
+    uint32_t L = 0;
+    while ((1u << L) < full_len / 2) L++;
+    GeomSpec sp[2];
+    scale_table_specs(F, host_powmod((uint32_t)offset, pp - 2, pp), host_powmod((uint32_t)omega, pp - 2, pp), L, sp);
+    std::vector<uint32_t> slo = fill(sp[0], F), shi = fill(sp[1], F);
+    const ScaleTables S{slo.data(), shi.data(), scale_table_h(L)};
+    const uint32_t inv2_m = (uint32_t)(((uint64_t)host_powmod(2, pp - 2, pp) << 32) % pp);
+    const uint32_t ah_m = fold_alpha_half(alpha, inv2_m, F);
+    for (uint32_t i = 0; i < count; i++) out[i] = fold_element(lo[i], hi[i], i0 + i, ah_m, inv2_m, S, F);
+    return 0;
+}

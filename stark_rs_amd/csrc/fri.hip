@@ -6,6 +6,7 @@
 // each root and draws alpha into device memory, the fold kernel reads alpha from there, so
 // a whole prove is enqueued without one host round trip; the host synchronises once to
 // copy the serialized proof back.
+#include "fri_core.h"
 #include "hash_core.h"
 #include "internal.h"
 
@@ -17,18 +18,13 @@ int launch_merkle(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_no
 // x_i^-1 comes from the two-level table S = offset^-1 * omega^-i; alpha is read from device
 // memory (unreduced u64, src/fiat_shamir.rs:23-24) and reduced here.  HBM-bound: 12 B in,
 // 4 B out per output element.
-__global__ __launch_bounds__(256) void fri_fold_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
-                                                       uint32_t half, const uint64_t *__restrict__ alpha_ptr, Fp F,
-                                                       ScaleTables S, uint32_t inv2_m) {
-    const uint32_t a = (uint32_t)(*alpha_ptr % F.p);
-    const uint32_t ah_m = mont_mul(to_mont(a, F), inv2_m, F);  // (alpha/2) in Montgomery form
+__global__ __launch_bounds__(256) void fri_fold_kernel(const uint32_t *__restrict__ lo, const uint32_t *__restrict__ hi,
+                                                       uint32_t *__restrict__ out, uint32_t count, uint32_t i0,
+                                                       const uint64_t *__restrict__ alpha_ptr, Fp F, ScaleTables S, uint32_t inv2_m) {
+    const uint32_t ah_m = fold_alpha_half(*alpha_ptr, inv2_m, F);
     const uint32_t step = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < half; i += step) {
-        const uint32_t x = in[i], y = in[i + half];
-        const uint32_t s = fp_add(x, y, F.p), d = fp_sub(x, y, F.p);
-        const uint32_t t_m = mont_mul(two_level(S.lo, S.hi, S.h, i, F), ah_m, F);
-        out[i] = fp_add(mont_mul(s, inv2_m, F), mont_mul(d, t_m, F), F.p);
-    }
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += step)
+        out[i] = fold_element(lo[i], hi[i], i0 + i, ah_m, inv2_m, S, F);
 }
 
 // ------------------------------------------------------------------------- Fiat-Shamir
@@ -252,22 +248,35 @@ void smi_fri_run_free(smi_fri_run *run) {
     delete run;
 }
 
-int launch_fold(smi_ctx *ctx, const uint32_t *d_in, size_t len, const uint64_t *d_alpha, uint64_t offset, uint64_t omega,
-                uint32_t *d_out) {
+// Folds `count` outputs starting at global index i0 of a codeword of length full_len:
+// out[k] = fold(lo[k], hi[k]) where lo[k] = c[i0+k], hi[k] = c[i0+k+full_len/2].
+static int launch_fold_shard(smi_ctx *ctx, const uint32_t *d_lo, const uint32_t *d_hi, size_t count, size_t i0, size_t full_len,
+                             const uint64_t *d_alpha, uint64_t offset, uint64_t omega, uint32_t *d_out) {
     const uint32_t p = ctx->fs.F.p;
-    if (len < 2 || !is_pow2(len)) return smi_fail(ctx, SMI_ERR_BAD_ARG, "fold: codeword length must be a power of two >= 2");
+    if (full_len < 2 || !is_pow2(full_len)) return smi_fail(ctx, SMI_ERR_BAD_ARG, "fold: codeword length must be a power of two >= 2");
+    if (i0 + count > full_len / 2) return smi_fail(ctx, SMI_ERR_BAD_ARG, "fold: shard outside the folded codeword");
     if (offset >= p || omega >= p) return smi_fail(ctx, SMI_ERR_NON_CANONICAL, "fold: offset/omega must be < p");
     if (offset == 0 || omega == 0) return smi_fail(ctx, SMI_ERR_DIV_BY_ZERO, "no division by zero");  // src/ff.rs:182
-    const uint32_t half = (uint32_t)(len / 2);
+    if (!count) return SMI_OK;
     ScaleTables S;
-    SMI_TRY(ctx_scale_tables(ctx, h_inv(ctx, (uint32_t)offset), h_inv(ctx, (uint32_t)omega), ilog2(half), &S));
+    SMI_TRY(ctx_scale_tables(ctx, h_inv(ctx, (uint32_t)offset), h_inv(ctx, (uint32_t)omega), ilog2(full_len / 2), &S));
     const uint32_t inv2_m = (uint32_t)(((uint64_t)h_inv(ctx, 2) << 32) % p);
-    uint32_t grid = (half + 255) / 256;
+    uint32_t grid = (uint32_t)((count + 255) / 256);
     if (grid > 2048) grid = 2048;
-    ProfScope ps(ctx, "fri_fold_kernel", 6.0 * (double)len);  // read L*4, write L/2*4
-    fri_fold_kernel<<<grid, 256, 0, ctx->stream>>>(d_in, d_out, half, d_alpha, ctx->fs.F, S, inv2_m);
+    ProfScope ps(ctx, "fri_fold_kernel", 12.0 * (double)count);  // read 2 x 4 B, write 4 B per output
+    fri_fold_kernel<<<grid, 256, 0, ctx->stream>>>(d_lo, d_hi, d_out, (uint32_t)count, (uint32_t)i0, d_alpha, ctx->fs.F, S, inv2_m);
     HIP_TRY(ctx, hipGetLastError());
     return SMI_OK;
+}
+int launch_fold(smi_ctx *ctx, const uint32_t *d_in, size_t len, const uint64_t *d_alpha, uint64_t offset, uint64_t omega,
+                uint32_t *d_out) {
+    if (len < 2 || !is_pow2(len)) return smi_fail(ctx, SMI_ERR_BAD_ARG, "fold: codeword length must be a power of two >= 2");
+    return launch_fold_shard(ctx, d_in, d_in + len / 2, len / 2, 0, len, d_alpha, offset, omega, d_out);
+}
+int smi_dev_fri_fold_shard(smi_ctx *ctx, const uint32_t *d_lo, const uint32_t *d_hi, size_t count, size_t index0, size_t full_len,
+                           const uint64_t *d_alpha, uint64_t offset, uint64_t omega, uint32_t *d_out) {
+    if (!ctx || !d_lo || !d_hi || !d_alpha || !d_out) return SMI_ERR_BAD_ARG;
+    return launch_fold_shard(ctx, d_lo, d_hi, count, index0, full_len, d_alpha, offset, omega, d_out);
 }
 
 // misc device block layout

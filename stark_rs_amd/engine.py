@@ -257,6 +257,10 @@ class Engine:
     def dev_fri_fold(self, d_in, length, d_alpha, offset, omega, d_out):
         self._ck(self.L.smi_dev_fri_fold(self.h, vp(d_in), length, vp(d_alpha), offset, omega, vp(d_out)))
 
+    def dev_fri_fold_shard(self, d_lo, d_hi, count, index0, full_len, d_alpha, offset, omega, d_out):
+        self._ck(self.L.smi_dev_fri_fold_shard(self.h, vp(d_lo), vp(d_hi), count, index0, full_len, vp(d_alpha), offset, omega,
+                                               vp(d_out)))
+
     def dev_fri_prove(self, cfg, d_codeword, length):
         proof, plen = vp(), C.c_size_t()
         top = np.zeros(max(cfg.num_colinearity_tests, 1), dtype=np.uint64)

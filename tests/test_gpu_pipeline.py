@@ -95,6 +95,21 @@ def test_transpose_and_fourstep_world1(eng2, oracle):
         assert np.array_equal(got, want)
 
 
+def test_sharded_commit_backend_world1(eng, oracle):
+    """stark_rs_amd/sharded.py with the HIP backend at world size 1 (the collectives are covered by
+    the gloo test): subtree kernel, device transcript hash and the shard fold entry point."""
+    from stark_rs_amd.sharded import HipShardBackend, ShardedFriCommit
+    o = oracle
+    n, exp, t, offset = 1 << 14, 8, 8, 3
+    omega = o.ff_prim_nth_root(n)
+    codeword = o.fast_coset_ntt(_vals(o, 5, n // exp), n, omega, offset)
+    be = HipShardBackend(eng)
+    roots, alphas, last = ShardedFriCommit(be, P, omega, offset, n, exp, t).commit(be.tensor(codeword))
+    wroots, walphas, wlast = o.fri_commit_trace(o.fri_cfg(omega, offset, n, exp, t), codeword)
+    assert roots == [bytes(r) for r in wroots] and alphas == walphas
+    assert np.array_equal(last.cpu().numpy().view(np.uint32).astype(np.uint64), wlast)
+
+
 def test_cfg3_full_size_lde_and_commit_properties(eng, oracle):
     """BASELINE configs[2]: 2^20-row x 4-column trace, blowup 8 (N = 2^23, the largest domain the
     reference prime has) + Merkle commit.  Size-independent properties: the extension agrees with
