@@ -167,6 +167,20 @@ def main():
         "roofline": roofline,
     }
 
+    # The headline line must survive anything the extra legs do: a watchdog thread prints what has
+    # been measured so far and hard-exits if an extra (e.g. a collective on a flaky peer) hangs.
+    import threading
+
+    def _bail():
+        result["extras_timeout"] = True
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+        os._exit(0)
+
+    watchdog = threading.Timer(420.0, _bail)
+    watchdog.daemon = True
+    watchdog.start()
+
     if not args.no_extras:
         # ---- end-to-end prove of the same trace (build-defined composition)
         try:
@@ -258,8 +272,9 @@ def main():
         if rank == 0 and world == 1:
             result["cpu_baseline"] = cpu_baseline()
 
+    watchdog.cancel()
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     eng.close()
     if distributed:
         dist.destroy_process_group()
