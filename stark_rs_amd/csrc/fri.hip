@@ -77,12 +77,15 @@ __global__ void fs_challenge_kernel(const FsState *fs, uint64_t *alpha_out) {
 }
 
 // Fri::sample_indices (src/fri.rs:176-213) with seed = Hash::from_u64(challenge).0
-// (src/fri.rs:272, src/hash.rs:37-39).  Single lane; `number` <= reduced_size is checked on
-// the host.  indices[0..number) = accepted (unreduced) indices; reduced[] is workspace.
-__global__ void sample_indices_kernel(const uint64_t *challenge, uint64_t size, uint64_t reduced_size, uint32_t number,
-                                      uint64_t *indices, uint64_t *reduced) {
-    if (threadIdx.x || blockIdx.x) return;
-    // seed = hash of the 8 LE bytes of the (unreduced) challenge
+// (src/fri.rs:272, src/hash.rs:37-39).  One wave: lane l hashes seed||counter for counter =
+// 64*batch + l, then lane 0 accepts candidates in counter order exactly like the reference's
+// sequential loop (distinct modulo reduced_size).  `number` <= reduced_size is checked on the host.
+__global__ __launch_bounds__(64) void sample_indices_kernel(const uint64_t *challenge, uint64_t size, uint64_t reduced_size,
+                                                            uint32_t number, uint64_t *indices, uint64_t *reduced) {
+    __shared__ uint64_t cand[64];
+    __shared__ uint32_t s_cnt;
+    const uint32_t lane = threadIdx.x;
+    // seed = hash of the 8 LE bytes of the (unreduced) challenge; every lane computes it (uniform)
     const uint64_t ch = *challenge;
     hashc::State st;
     hashc::init(st);
@@ -92,12 +95,13 @@ __global__ void sample_indices_kernel(const uint64_t *challenge, uint64_t size, 
     for (int k = 0; k < 8; k++) hashc::mix(st);
     uint32_t seed[8];
     hashc::to_words(st, seed);
-    // state after the first chunk (= seed) of every seed||counter message
-    hashc::State base;
+    hashc::State base;   // state after the first chunk (= seed) of every seed||counter message
     hashc::init(base);
     hashc::absorb_chunk32(base, seed);
-    uint32_t cnt = 0, counter = 0;
-    while (cnt < number) {
+    if (lane == 0) s_cnt = 0;
+    __syncthreads();
+    for (uint32_t batch = 0; batch < (1u << 20); batch++) {   // bounded: ends as soon as `number` are accepted
+        const uint32_t counter = batch * 64u + lane;
         hashc::State s2 = base;
 #pragma unroll
         for (int i = 0; i < 4; i++) hashc::absorb_byte(s2, i, (counter >> (8 * i)) & 0xFFu);
@@ -110,15 +114,24 @@ __global__ void sample_indices_kernel(const uint64_t *challenge, uint64_t size, 
         uint64_t acc = 0;
 #pragma unroll
         for (int i = 24; i < 32; i++) acc = (acc << 8) | ((d[i >> 2] >> (8 * (i & 3))) & 0xFFu);
-        const uint64_t index = acc % size, ri = index % reduced_size;
-        counter++;
-        bool seen = false;
-        for (uint32_t k = 0; k < cnt; k++) seen |= reduced[k] == ri;
-        if (!seen) {
-            indices[cnt] = index;
-            reduced[cnt] = ri;
-            cnt++;
+        cand[lane] = acc % size;
+        __syncthreads();
+        if (lane == 0) {
+            uint32_t cnt = s_cnt;
+            for (uint32_t k = 0; k < 64 && cnt < number; k++) {
+                const uint64_t index = cand[k], ri = index % reduced_size;
+                bool seen = false;
+                for (uint32_t j = 0; j < cnt; j++) seen |= reduced[j] == ri;
+                if (!seen) {
+                    indices[cnt] = index;
+                    reduced[cnt] = ri;
+                    cnt++;
+                }
+            }
+            s_cnt = cnt;
         }
+        __syncthreads();
+        if (s_cnt >= number) break;
     }
 }
 

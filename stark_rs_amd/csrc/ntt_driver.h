@@ -25,7 +25,7 @@ struct NttRequest {
 //   void pass(int logr, int logw, bool last, const PassArgs&, uint32_t batch);
 //   const Tw2 *pass_table(uint32_t mlog, uint32_t logr);   // w_m^(k*b) table (cached), or nullptr
 template <class Launcher> inline void ntt_run(Launcher &ln, const NttRequest &rq) {
-    const NttPlan pl = ntt_make_plan(rq.L);
+    const NttPlan pl = ntt_make_plan(rq.L, rq.batch);
     if (pl.np == 0) {
         SmallArgs a;
         a.in = rq.in; a.out = rq.out; a.in_stride = rq.in_stride; a.out_stride = rq.out_stride;

@@ -45,7 +45,7 @@ inline bool ntt_plan_valid(uint32_t L, const NttPlan &pl) {
     return pl.logr[0] >= pl.logw[pl.np - 1];
 }
 
-inline NttPlan ntt_make_plan(uint32_t L) {
+inline NttPlan ntt_make_plan(uint32_t L, uint32_t batch = 1) {
     NttPlan pl;
     memset(&pl, 0, sizeof pl);
     if (L <= SMI_TILE_LOG) return pl;  // np = 0
@@ -79,8 +79,13 @@ inline NttPlan ntt_make_plan(uint32_t L) {
         const bool last = i == pl.np - 1;
         const int limit = last ? pl.logr[0] : (int)L - consumed;
         int best = -1;
-        for (int lw = 2; lw <= 6; lw++)
-            if (ntt_shape_ok(pl.logr[i], lw) && lw <= limit && pl.logr[i] + lw <= (last ? 13 : 14) && lw <= 5) best = lw;
+        for (int lw = 2; lw <= 6; lw++) {
+            if (!ntt_shape_ok(pl.logr[i], lw) || lw > limit || pl.logr[i] + lw > (last ? 13 : 14) || lw > 5) continue;
+            // small problems: keep at least ~2 workgroups per CU in flight rather than wide lines
+            const uint64_t tiles = ((uint64_t)batch << L) >> (pl.logr[i] + lw);
+            if (best >= 0 && tiles < 512) continue;
+            best = lw;
+        }
         if (best < 0)
             for (int lw = 6; lw >= 2; lw--)
                 if (ntt_shape_ok(pl.logr[i], lw) && lw <= limit) best = lw;
