@@ -275,3 +275,63 @@ def test_fri_panics(eng, oracle):
     cfg = eng.fri_cfg(o.ff_prim_nth_root(32), 3, 32, 4, 2)
     with pytest.raises(s.StarkMiError, match="initial codeword length does not match domain length"):
         eng.fri_prove(cfg, [5] * 16)
+
+
+# ------------------------------------------------------------------ edge cases
+def test_edge_empty_and_tiny_inputs(eng, oracle):
+    import stark_rs_amd as s
+    o = oracle
+    # eval_domain of the empty polynomial is all zeros (eval.rs:36-41 `test_eval_zero_poly`)
+    assert not eng.coset_ntt([], 6, 3).any()
+    assert not eng.coset_ntt([], 14, 1).any()
+    # a single coefficient / a single point
+    assert list(eng.coset_ntt([7], 0, 5)) == [7] and list(eng.intt([9], 4)) == [9]
+    assert list(eng.coset_ntt([7], 5, 3)) == [7] * 32                      # constant polynomial (eval.rs:44-51)
+    # all-zero values interpolate to all-zero coefficients (the mirror maps that to `vec![]`, H8)
+    assert not eng.intt(np.zeros(1 << 13, dtype=np.uint64), 3).any()
+    # FRI configurations the reference's verify would reject up front: no rounds at all
+    with pytest.raises(s.StarkMiError, match="No FRI roots extracted"):
+        eng.fri_prove(eng.fri_cfg(o.ff_prim_nth_root(8), 3, 8, 8, 1), [1] * 8)
+    # an all-zero codeword is a valid (degree -1) codeword: byte-identical proof
+    n = 64
+    cfg, ocfg = eng.fri_cfg(o.ff_prim_nth_root(n), 3, n, 4, 3), o.fri_cfg(o.ff_prim_nth_root(n), 3, n, 4, 3)
+    assert eng.fri_prove(cfg, [0] * n)[0] == o.fri_prove(ocfg, [0] * n)[0]
+
+
+@pytest.mark.parametrize("log_blowup", [1, 2, 3, 4])
+@pytest.mark.parametrize("logn", [10, 14])
+def test_lde_every_blowup(eng, oracle, logn, log_blowup):
+    """Zero-padded first passes specialise on the padding factor (2, 4, 8, 16): all of them, on a
+    single-kernel size and on a multi-pass size."""
+    o = oracle
+    n, N = 1 << logn, 1 << (logn + log_blowup)
+    w, W = o.ff_prim_nth_root(n), o.ff_prim_nth_root(N)
+    cols = np.stack([_vals(o, 900 + c, n) for c in range(2)])
+    out = eng.lde(cols, log_blowup, 1, 3)
+    for c in range(2):
+        assert np.array_equal(out[c], o.fast_coset_ntt(o.fast_intt(cols[c], w, 1), N, W, 3))
+
+
+def test_ragged_coefficient_counts(eng, oracle):
+    """eval_domain with coefficient counts that are not powers of two (zero padding at any length)."""
+    o = oracle
+    for logN, nc in ((13, 1), (13, 5), (13, 1000), (13, 8191), (16, 8193), (16, 65535)):
+        N = 1 << logN
+        W = o.ff_prim_nth_root(N)
+        c = _vals(o, nc, nc)
+        assert np.array_equal(eng.coset_ntt(c, logN, 3), o.fast_coset_ntt(c, N, W, 3)), (logN, nc)
+
+
+def test_max_size_second_prime_2p26_sampled(eng2, oracle):
+    """The largest domain of the second prime (BASELINE configs[3] size): 2^26 points, checked by
+    the round trip and by the op-for-op oracle's Polynomial::eval at sampled points."""
+    o = oracle
+    logn = 26
+    n = 1 << logn
+    w = o.ff_prim_nth_root_g(n, P2, G2)
+    coeffs = _vals(o, 26, 1 << 16, P2)                      # degree < 2^16 keeps the oracle's eval cheap
+    ev = eng2.coset_ntt(coeffs, logn, 5)
+    for k in (0, 1, 3, n // 3, n - 1):
+        assert o.poly_eval(coeffs, o.ff_mul(5, o.ff_exp(w, k, P2), P2), P2) == int(ev[k])
+    back = eng2.intt(ev, 5)
+    assert np.array_equal(back[: 1 << 16], coeffs) and not back[1 << 16:].any()
