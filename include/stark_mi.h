@@ -150,6 +150,10 @@ int smi_merkle_root(smi_ctx *ctx, const smi_tree *t, uint8_t root[32]);         
 int smi_merkle_open(smi_ctx *ctx, const smi_tree *t, size_t index, uint8_t *path, size_t *depth);
 /* Copies level `level` (0 = leaves) to the host: nodes[level] of src/merkle.rs:6. */
 int smi_merkle_level(smi_ctx *ctx, const smi_tree *t, uint32_t level, uint8_t *out, size_t *n_out);
+/* MerkleTree::verify (src/merkle.rs:82-96) for k (leaf, index, path) triples that share one depth
+ * and one root -- the verifier's hot loop (src/fri.rs:464-497); ok[i] = 1 if path i authenticates. */
+int smi_merkle_verify_batch(smi_ctx *ctx, const uint8_t *leaves, const uint64_t *indices, const uint8_t *paths, size_t k,
+                            size_t depth, const uint8_t root[32], uint8_t *ok);
 size_t smi_merkle_num_leaves(const smi_tree *t);
 void smi_merkle_free(smi_tree *t);
 

@@ -110,6 +110,7 @@ def lib():
         "smi_merkle_root": (i32, [vp, vp, vp]),
         "smi_merkle_open": (i32, [vp, vp, sz, vp, C.POINTER(sz)]),
         "smi_merkle_level": (i32, [vp, vp, C.c_uint32, vp, C.POINTER(sz)]),
+        "smi_merkle_verify_batch": (i32, [vp, vp, vp, vp, sz, sz, vp, vp]),
         "smi_merkle_num_leaves": (sz, [vp]),
         "smi_merkle_free": (None, [vp]),
         "smi_fri_check": (i32, [vp, C.POINTER(FriCfg)]),

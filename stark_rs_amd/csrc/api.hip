@@ -6,6 +6,8 @@ int launch_leaf_hash(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d
 int launch_combine(smi_ctx *ctx, const uint8_t *d_in, size_t n_pairs, uint8_t *d_out);
 int launch_hash_bytes(smi_ctx *ctx, const uint8_t *d_msg, size_t len, uint32_t *d_out);
 int launch_merkle(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_nodes);
+int launch_verify_paths(smi_ctx *ctx, const uint8_t *d_leaves, const uint64_t *d_idx, const uint8_t *d_paths, size_t k, uint32_t depth,
+                        const uint8_t *d_root, uint8_t *d_ok);
 
 // ------------------------------------------------------------------------- errors
 const char *smi_status_string(int status) {
@@ -630,6 +632,25 @@ int smi_merkle_level(smi_ctx *ctx, const smi_tree *t, uint32_t level, uint8_t *o
     HIP_TRY(ctx, hipMemcpyAsync(out, t->d_nodes + off * 32, cnt * 32, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (n_out) *n_out = cnt;
+    return SMI_OK;
+}
+int smi_merkle_verify_batch(smi_ctx *ctx, const uint8_t *leaves, const uint64_t *indices, const uint8_t *paths, size_t k, size_t depth,
+                            const uint8_t root[32], uint8_t *ok) {
+    if (!ctx || !root || (k && (!leaves || !indices || !ok || (depth && !paths)))) return SMI_ERR_BAD_ARG;
+    if (!k) return SMI_OK;
+    if (depth > 64) return smi_fail(ctx, SMI_ERR_BAD_ARG, "verify: path deeper than 64");
+    const size_t b_leaves = k * 32, b_idx = k * 8, b_paths = k * depth * 32;
+    void *d_in, *d_ok;
+    SMI_TRY(ctx_tmp(ctx, 1, b_leaves + b_idx + b_paths + 32 + 64, &d_in));
+    SMI_TRY(ctx_tmp(ctx, 2, k, &d_ok));
+    uint8_t *base = (uint8_t *)d_in, *dl = base, *di = dl + b_leaves, *dp = di + b_idx, *dr = dp + ((b_paths + 15) & ~(size_t)15);
+    HIP_TRY(ctx, hipMemcpyAsync(dl, leaves, b_leaves, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(di, indices, b_idx, hipMemcpyHostToDevice, ctx->stream));
+    if (b_paths) HIP_TRY(ctx, hipMemcpyAsync(dp, paths, b_paths, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dr, root, 32, hipMemcpyHostToDevice, ctx->stream));
+    SMI_TRY(launch_verify_paths(ctx, dl, (const uint64_t *)di, dp, k, (uint32_t)depth, dr, (uint8_t *)d_ok));
+    HIP_TRY(ctx, hipMemcpyAsync(ok, d_ok, k, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return SMI_OK;
 }
 size_t smi_merkle_num_leaves(const smi_tree *t) { return t ? t->n : 0; }

@@ -84,6 +84,32 @@ __global__ __launch_bounds__(SMI_HASH_THREADS) void combine_kernel(const uint4 *
     out[2 * i + 1] = make_uint4(d[4], d[5], d[6], d[7]);
 }
 
+// MerkleTree::verify (src/merkle.rs:82-96) for k (leaf, index, path) triples against one root
+__global__ __launch_bounds__(SMI_HASH_THREADS) void verify_paths_kernel(const uint4 *__restrict__ leaves, const uint64_t *__restrict__ indices,
+                                                                          const uint4 *__restrict__ paths, size_t k, uint32_t depth,
+                                                                          const uint4 *__restrict__ root, uint8_t *ok) {
+    const size_t i = (size_t)blockIdx.x * SMI_HASH_THREADS + threadIdx.x;
+    if (i >= k) return;
+    uint4 a = leaves[2 * i], b = leaves[2 * i + 1];
+    uint32_t cur[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint64_t idx = indices[i];
+    for (uint32_t d = 0; d < depth; d++) {
+        a = paths[2 * (i * depth + d)];
+        b = paths[2 * (i * depth + d) + 1];
+        const uint32_t sib[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        uint32_t nxt[8];
+        if (idx % 2 == 0) hashc::node_hash(cur, sib, nxt);
+        else hashc::node_hash(sib, cur, nxt);
+#pragma unroll
+        for (int w = 0; w < 8; w++) cur[w] = nxt[w];
+        idx /= 2;
+    }
+    a = root[0];
+    b = root[1];
+    ok[i] = cur[0] == a.x && cur[1] == a.y && cur[2] == a.z && cur[3] == a.w && cur[4] == b.x && cur[5] == b.y && cur[6] == b.z &&
+            cur[7] == b.w;
+}
+
 // Hash::from_bytes of one message, single lane (src/hash.rs:7-30)
 __global__ void hash_bytes_kernel(const uint8_t *msg, size_t len, uint32_t *out) {
     if (threadIdx.x || blockIdx.x) return;
@@ -104,6 +130,14 @@ int launch_leaf_hash(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d
 int launch_combine(smi_ctx *ctx, const uint8_t *d_in, size_t n_pairs, uint8_t *d_out) {
     if (!n_pairs) return SMI_OK;
     combine_kernel<<<blocks_for(n_pairs), SMI_HASH_THREADS, 0, ctx->stream>>>((const uint4 *)d_in, (uint4 *)d_out, n_pairs);
+    HIP_TRY(ctx, hipGetLastError());
+    return SMI_OK;
+}
+int launch_verify_paths(smi_ctx *ctx, const uint8_t *d_leaves, const uint64_t *d_idx, const uint8_t *d_paths, size_t k, uint32_t depth,
+                        const uint8_t *d_root, uint8_t *d_ok) {
+    if (!k) return SMI_OK;
+    verify_paths_kernel<<<blocks_for(k), SMI_HASH_THREADS, 0, ctx->stream>>>((const uint4 *)d_leaves, d_idx, (const uint4 *)d_paths, k, depth,
+                                                                              (const uint4 *)d_root, d_ok);
     HIP_TRY(ctx, hipGetLastError());
     return SMI_OK;
 }

@@ -165,6 +165,18 @@ class Engine:
         self._ck(self.L.smi_merkle_commit(self.h, l.ctypes.data, len(l), out))
         return bytes(out)
 
+    def merkle_verify_batch(self, leaves, indices, paths, root):
+        """MerkleTree::verify for k triples sharing one depth and root -> bool array."""
+        l = np.ascontiguousarray(leaves, dtype=np.uint8).reshape(-1, 32)
+        k = len(l)
+        pth = np.ascontiguousarray(paths, dtype=np.uint8).reshape(k, -1, 32) if k else np.zeros((0, 0, 32), np.uint8)
+        idx = _u64(indices)
+        ok = np.zeros(max(k, 1), dtype=np.uint8)
+        rt = np.frombuffer(bytes(root), dtype=np.uint8).copy()
+        self._ck(self.L.smi_merkle_verify_batch(self.h, l.ctypes.data, idx.ctypes.data, pth.ctypes.data, k, pth.shape[1],
+                                                rt.ctypes.data, ok.ctypes.data))
+        return ok[:k].astype(bool)
+
     def merkle_new(self, leaves):
         l = np.ascontiguousarray(leaves, dtype=np.uint8).reshape(-1, 32)
         t = vp()

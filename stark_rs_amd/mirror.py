@@ -469,6 +469,110 @@ class Fri:
         return top
 
 
+def _fri_verify(self, proof_stream, fiat_shamir, polynomial_values):
+    """Fri::verify (src/fri.rs:313-504): host control flow as in the reference; the heavy parts run
+    on the device -- leaf hashes and Merkle paths in batches (smi_hash_leaves,
+    smi_merkle_verify_batch) and the last-layer interpolation as an inverse NTT instead of the
+    reference's O(L^3) Lagrange.  Returns False where the reference prints + returns false."""
+    field, p, t = self.field, self.field.p, self.num_colinearity_tests
+    eng = self._eng
+    omega, offset = self.omega.value, self.offset.value
+    R = self.num_rounds()
+    roots, alphas = [], []
+    for _ in range(R):                                                      # :325-334
+        o = proof_stream.pop()
+        if o is None or o.tag != ProofObject.MERKLE_ROOT:
+            return False
+        roots.append(o.payload)
+        fiat_shamir.absorb(o.payload.bytes)
+        alphas.append(fiat_shamir.challenge(field).value)
+    o = proof_stream.pop()                                                   # :337-342
+    if o is None or o.tag != ProofObject.FIELD_ELEMENTS:
+        return False
+    last = [fe.value for fe in o.payload]
+    if not roots:
+        return False                                                         # "No FRI roots extracted"
+    n_last = len(last)
+    if n_last == 0 or n_last & (n_last - 1):
+        raise StarkMiError(-6, "Number of leaves must be power of 2")       # MerkleTree::new at :353
+    if eng.merkle_commit(eng.hash_leaves(last)) != roots[-1].bytes:          # :349-357
+        return False
+    degree_bound = n_last // self.expansion_factor                            # :360-365
+    if degree_bound == 0:
+        return False
+    last_omega, last_offset = omega, offset
+    for _ in range(R - 1):
+        last_omega, last_offset = last_omega * last_omega % p, last_offset * last_offset % p
+    coeffs = eng.intt(np.array(last, dtype=np.uint64), last_offset) if n_last > 1 else np.array(last, dtype=np.uint64)
+    # the iNTT needs last_omega to be the canonical n_last-th root; the round trip below is the
+    # reference's own re-evaluation check (:384-390) and fails otherwise
+    re_eval = eng.coset_ntt(coeffs, n_last.bit_length() - 1, last_offset)
+    if last_omega != eng.prim_nth_root(n_last) or [int(v) for v in re_eval] != last:
+        return False
+    nz = np.nonzero(coeffs)[0]
+    if len(nz) and int(nz[-1]) > degree_bound - 1:                            # :392-397
+        return False
+    seed = Hash.from_u64(fiat_shamir.challenge(field).value).bytes            # :400-405
+    top = self.sample_indices(seed, self.domain_length >> 1, self.domain_length >> (R - 1), t)
+    for r in range(R - 1):                                                    # :408-502
+        half = self.domain_length >> (r + 1)
+        c_idx = [i % half for i in top]
+        aa, bb, cc = [], [], []
+        for s_ in range(t):
+            o = proof_stream.pop()
+            if o is None or o.tag != ProofObject.FIELD_ELEMENTS or len(o.payload) != 3:
+                return False
+            ay, by, cy = (fe.value for fe in o.payload)
+            aa.append(ay); bb.append(by); cc.append(cy)
+            if r == 0:
+                polynomial_values.append((c_idx[s_], field.new_element(ay)))
+                polynomial_values.append((c_idx[s_] + half, field.new_element(by)))
+            ax = offset * pow(omega, c_idx[s_], p) % p
+            bx = offset * pow(omega, c_idx[s_] + half, p) % p
+            cx = alphas[r]                                                    # unreduced, like :452
+            # test_colinearity (:507-525): (y1-y0)(x2-x0) == (y2-y0)(x1-x0)
+            if ((p + by - ay) % p) * ((p + cx - ax) % p) % p != ((p + cy - ay) % p) * ((p + bx - ax) % p) % p:
+                return False
+        paths = []
+        for _ in range(3 * t):
+            o = proof_stream.pop()
+            if o is None or o.tag != ProofObject.MERKLE_PATH:
+                return False
+            paths.append(b"".join(h.bytes for h in o.payload))
+        for vals, idxs, sel, root in ((aa, c_idx, 0, roots[r]), (bb, [i + half for i in c_idx], 1, roots[r]),
+                                      (cc, c_idx, 2, roots[r + 1])):
+            mine = [paths[3 * i + sel] for i in range(t)]
+            depth = len(mine[0]) // 32 if mine else 0
+            if any(len(m_) != depth * 32 for m_ in mine):
+                return False
+            ok = eng.merkle_verify_batch(eng.hash_leaves(vals), idxs, np.frombuffer(b"".join(mine), dtype=np.uint8), root.bytes)
+            if not ok.all():
+                return False
+        omega, offset = omega * omega % p, offset * offset % p
+    return True
+
+
+def _fri_sample_indices(self, seed, size, reduced_size, number):
+    """Fri::sample_indices (src/fri.rs:176-213); digests come from the device hash kernel."""
+    if number > 2 * reduced_size:
+        raise StarkMiError(-12, "not enough entropy in indices wrt last codeword")
+    if number > reduced_size:
+        raise StarkMiError(-13, "cannot sample more indices than available in last codeword")
+    indices, reduced, counter = [], [], 0
+    while len(indices) < number:
+        h = Hash.from_bytes(bytes(seed) + counter.to_bytes(4, "little")).bytes
+        index = int.from_bytes(h[24:], "big") % size                          # sample_index, :168-174
+        counter += 1
+        if index % reduced_size not in reduced:
+            indices.append(index)
+            reduced.append(index % reduced_size)
+    return indices
+
+
+Fri.verify = _fri_verify
+Fri.sample_indices = _fri_sample_indices
+
+
 class Trace:
     """src/trace.rs:3-50"""
 

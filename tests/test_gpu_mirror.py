@@ -178,7 +178,16 @@ def test_fri_prove_verify(m, field, oracle, n, expansion, t, offset, coeffs):
     top = fri.prove(list(codeword), prover_fiat_shamir, proof_stream)
     assert len(top) == t
     proof_bytes = proof_stream.serialize()
-    # the reference's Fri::verify (CPU, restated by the oracle) on the deserialized stream
+    # the reference test's own ending: deserialize, then Fri::verify with a fresh FiatShamir
+    verifier_stream = m.ProofStream.deserialize(proof_bytes, f)
+    verifier_fiat_shamir = m.FiatShamir.new()
+    polynomial_values = []
+    assert fri.verify(verifier_stream, verifier_fiat_shamir, polynomial_values), "FRI verification should succeed"
+    assert len(polynomial_values) == 2 * t and all(codeword[i] == v for i, v in polynomial_values)
+    bad = bytearray(proof_bytes)
+    bad[-40] ^= 1
+    assert not fri.verify(m.ProofStream.deserialize(bytes(bad), f), m.FiatShamir.new(), [])
+    # ... and the oracle's restatement of Fri::verify agrees
     assert m.ProofStream.deserialize(proof_bytes, f).serialize() == proof_bytes
     ocfg = oracle.fri_cfg(omega.value, offset, n, expansion, t)
     assert oracle.fri_verify(ocfg, proof_bytes), oracle.fri_last_reject()
