@@ -101,6 +101,15 @@ SMI_HD uint32_t two_level(const uint32_t *lo, const uint32_t *hi, uint32_t h, ui
     return mont_mul(lo[e & ((1u << h) - 1u)], hi[e >> h], F);
 }
 
+// Global accesses as wave-uniform base + 32-bit byte offset (all tile-relative offsets stay below
+// 2^30 elements): lets the compiler use the SGPR-base addressing form instead of a 64-bit
+// vector add per access.
+SMI_HD uint32_t ld32(const uint32_t *base, uint32_t idx) {
+    return *(const uint32_t *)((const char *)base + (size_t)(uint32_t)(idx << 2));
+}
+SMI_HD void st32(uint32_t *base, uint32_t idx, uint32_t v) { *(uint32_t *)((char *)base + (size_t)(uint32_t)(idx << 2)) = v; }
+SMI_HD Tw2 ld_tw(const Tw2 *base, uint32_t idx) { return *(const Tw2 *)((const char *)base + (size_t)(uint32_t)(idx << 3)); }
+
 // ---- lazy arithmetic on [0, 2p), p < 2^30
 SMI_HD uint32_t lz_add(uint32_t a, uint32_t b, uint32_t p2) {
     const uint32_t s = a + b;          // < 4p < 2^32
@@ -207,7 +216,7 @@ template <int LOGR, int LOGW, bool LAST> struct NttPass {
             for (int i = 0; i < V; i++) {
                 if (i >= (V >> Z)) { v[i] = 0u; continue; }
                 const uint32_t g = t.b0 + o0 + ((uint32_t)(i * (NT >> LOGW)) << blog);
-                const uint32_t x = col[g < a.n_in ? g : 0u];
+                const uint32_t x = ld32(col, g < a.n_in ? g : 0u);
                 v[i] = g < a.n_in ? x : 0u;
             }
             if (a.flags & NTT_PRE_SCALE) {
@@ -223,7 +232,7 @@ template <int LOGR, int LOGW, bool LAST> struct NttPass {
         } else {
             const uint32_t *in = a.in + (uint64_t)batch * a.in_stride + t.in_base;
 #pragma unroll
-            for (int i = 0; i < V; i++) v[i] = in[o0 + ((uint32_t)(i * (NT >> LOGW)) << blog)];
+            for (int i = 0; i < V; i++) v[i] = ld32(in, o0 + ((uint32_t)(i * (NT >> LOGW)) << blog));
         }
     }
 
@@ -249,7 +258,7 @@ template <int LOGR, int LOGW, bool LAST> struct NttPass {
         for (int i = 0; i < V; i++) {
             const uint32_t idx = tid + i * NT;
             const uint32_t j = idx & (R - 1), l = idx >> LOGR;
-            v[i] = in[(l << (arest_log + LOGR)) + j];
+            v[i] = ld32(in, (l << (arest_log + LOGR)) + j);
         }
 #pragma unroll
         for (int i = 0; i < V; i++) {
@@ -339,7 +348,7 @@ template <int LOGR, int LOGW, bool LAST> struct NttPass {
 #pragma unroll
                     for (int kk = 0; kk < RL; kk++) {
                         const uint32_t o = o0 + ((uint32_t)kk << (KSTEP_LOG + blog));
-                        out[o] = lz_canon(shoup_mul(x[brev<SL>(kk)], tab[o], p), p);
+                        st32(out, o, lz_canon(shoup_mul(x[brev<SL>(kk)], ld_tw(tab, o), p), p));
                     }
                 } else {
                     // first pass (m = n: a table would double the traffic): w_m^(k*b) = g^k, g = w_m^b;
@@ -348,7 +357,7 @@ template <int LOGR, int LOGW, bool LAST> struct NttPass {
                     if (bi + 1 < NB) base_run = mont_mul_c(base_run, gbi, gbq, a.F);
 #pragma unroll
                     for (int kk = 0; kk < RL; kk++) {
-                        out[o0 + ((uint32_t)kk << (KSTEP_LOG + blog))] = mont_mul(x[brev<SL>(kk)], cur, a.F);
+                        st32(out, o0 + ((uint32_t)kk << (KSTEP_LOG + blog)), mont_mul(x[brev<SL>(kk)], cur, a.F));
                         if (kk + 1 < RL) cur = mont_mul_c(cur, gs, gq, a.F);
                     }
                 }
@@ -359,12 +368,12 @@ template <int LOGR, int LOGW, bool LAST> struct NttPass {
                     if (bi + 1 < NB) sc_run = mont_mul_c(sc_run, a.post_bi_ratio_m, rbq, a.F);
 #pragma unroll
                     for (int kk = 0; kk < RL; kk++) {
-                        out[o0 + ((uint32_t)kk << (KSTEP_LOG + a.Sp))] = mont_mul(x[brev<SL>(kk)], sc, a.F);
+                        st32(out, o0 + ((uint32_t)kk << (KSTEP_LOG + a.Sp)), mont_mul(x[brev<SL>(kk)], sc, a.F));
                         if (kk + 1 < RL) sc = mont_mul_c(sc, a.post_ratio_m, rq, a.F);
                     }
                 } else {
 #pragma unroll
-                    for (int kk = 0; kk < RL; kk++) out[o0 + ((uint32_t)kk << (KSTEP_LOG + a.Sp))] = lz_canon(x[brev<SL>(kk)], p);
+                    for (int kk = 0; kk < RL; kk++) st32(out, o0 + ((uint32_t)kk << (KSTEP_LOG + a.Sp)), lz_canon(x[brev<SL>(kk)], p));
                 }
             }
         }
