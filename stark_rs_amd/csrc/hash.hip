@@ -20,8 +20,11 @@ __device__ __forceinline__ size_t level_offset(size_t n, uint32_t lvl) { return 
 template <bool FROM_ELEMS>
 __global__ __launch_bounds__(SMI_HASH_THREADS) void merkle_sub_kernel(const uint32_t *__restrict__ elems, uint4 *nodes,
                                                                         size_t n, uint32_t lvl_in, size_t count_in,
-                                                                        uint32_t K) {
+                                                                        uint32_t K, size_t elem_stride, size_t node_stride) {
     extern __shared__ __attribute__((aligned(16))) uint32_t stash[];  // [1<<K][8][SMI_HASH_THREADS]
+    // blockIdx.y = tree of a batch of equally sized trees (e.g. the columns of a trace)
+    elems += (size_t)blockIdx.y * elem_stride;
+    nodes += (size_t)blockIdx.y * node_stride;
     const uint32_t tid = threadIdx.x;
     const size_t t = (size_t)blockIdx.x * SMI_HASH_THREADS + tid;
     const size_t n_threads = count_in >> K;
@@ -155,7 +158,17 @@ static uint32_t log2_floor(size_t n) {
 
 // Builds levels (lvl_from, log2 n] of the tree in d_nodes; if d_elems != nullptr level 0 is
 // hashed from the codeword first (fused with the bottom levels).  n must be a power of two.
+int launch_merkle_batch(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_nodes, uint32_t n_trees, size_t elem_stride,
+                        size_t node_stride_bytes);
 int launch_merkle(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_nodes) {
+    return launch_merkle_batch(ctx, d_elems, n, d_nodes, 1, 0, 0);
+}
+// n_trees equally sized trees in one set of launches: tree y reads d_elems + y*elem_stride and writes
+// d_nodes + y*node_stride_bytes.  The small upper levels of all trees share their launch latency.
+int launch_merkle_batch(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_nodes, uint32_t n_trees, size_t elem_stride,
+                        size_t node_stride_bytes) {
+    if (!n_trees) return SMI_OK;
+    const size_t node_stride = node_stride_bytes / 16;
     const uint32_t depth = log2_floor(n);
     uint4 *nodes = (uint4 *)d_nodes;
     uint32_t lvl = 0;
@@ -166,7 +179,10 @@ int launch_merkle(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_no
         const int k = e ? atoi(e) : 2;
         return (uint32_t)(k < 1 ? 1 : (k > 3 ? 3 : k));
     }();
-    if (from_elems && depth == 0) return launch_leaf_hash(ctx, d_elems, 1, d_nodes);
+    if (from_elems && depth == 0) {
+        for (uint32_t y = 0; y < n_trees; y++) SMI_TRY(launch_leaf_hash(ctx, d_elems + y * elem_stride, 1, d_nodes + y * node_stride_bytes));
+        return SMI_OK;
+    }
     while (lvl < depth || from_elems) {
         uint32_t K = depth - lvl < KMAX ? depth - lvl : KMAX;
         const size_t threads = count >> K;
@@ -174,11 +190,12 @@ int launch_merkle(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_no
         // algorithmic bytes: inputs read once (4 B elements or 32 B digests), every produced digest written once
         const double produced = from_elems ? (double)count * 2.0 - (double)(count >> K) : (double)count - (double)(count >> K);
         ProfScope ps(ctx, from_elems ? "merkle_sub_kernel<leaves>" : "merkle_sub_kernel<digests>",
-                     (from_elems ? 4.0 : 32.0) * (double)count + 32.0 * produced);
+                     ((from_elems ? 4.0 : 32.0) * (double)count + 32.0 * produced) * n_trees);
+        const dim3 grid(blocks_for(threads), n_trees);
         if (from_elems)
-            merkle_sub_kernel<true><<<blocks_for(threads), SMI_HASH_THREADS, lds, ctx->stream>>>(d_elems, nodes, n, 0, count, K);
+            merkle_sub_kernel<true><<<grid, SMI_HASH_THREADS, lds, ctx->stream>>>(d_elems, nodes, n, 0, count, K, elem_stride, node_stride);
         else
-            merkle_sub_kernel<false><<<blocks_for(threads), SMI_HASH_THREADS, lds, ctx->stream>>>(nullptr, nodes, n, lvl, count, K);
+            merkle_sub_kernel<false><<<grid, SMI_HASH_THREADS, lds, ctx->stream>>>(nullptr, nodes, n, lvl, count, K, 0, node_stride);
         HIP_TRY(ctx, hipGetLastError());
         from_elems = false;
         lvl += K;

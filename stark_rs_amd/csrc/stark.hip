@@ -15,7 +15,8 @@
 #include "hash_core.h"
 #include "internal.h"
 
-int launch_merkle(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_nodes);
+int launch_merkle_batch(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_nodes, uint32_t n_trees, size_t elem_stride,
+                        size_t node_stride_bytes);
 int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, size_t len, bool do_query, bool reset_arena,
             smi_fri_run **run_out, std::vector<uint8_t> *proof_host, uint64_t *top_host, uint8_t *roots_host,
             uint64_t *alphas_host, uint64_t *last_host, size_t *last_len);
@@ -89,14 +90,18 @@ int smi_dev_stark_prove(smi_ctx *ctx, const smi_stark_cfg *cfg, const uint32_t *
     if (!d_lde || !d_cw || !d_weights || !d_rootp) return smi_fail(ctx, SMI_ERR_OOM, "stark_prove: device memory");
     std::vector<uint8_t *> trees(W);
     std::vector<const uint8_t *> rootp(W);
+    // the W column trees sit back to back (stride 2N digests) so one set of launches builds them all
+    const size_t tree_stride = 2 * N * 32;
+    uint8_t *tree_base = (uint8_t *)arena_alloc(ctx, tree_stride * W);
+    if (!tree_base) return smi_fail(ctx, SMI_ERR_OOM, "stark_prove: tree memory");
     for (uint32_t c = 0; c < W; c++) {
-        if (!(trees[c] = (uint8_t *)arena_alloc(ctx, (2 * N - 1) * 32))) return smi_fail(ctx, SMI_ERR_OOM, "stark_prove: tree memory");
+        trees[c] = tree_base + c * tree_stride;
         rootp[c] = trees[c] + (2 * N - 2) * 32;
     }
     mark(0);
     SMI_TRY(smi_dev_lde(ctx, d_trace_cols, W, cfg->log_n, cfg->log_blowup, cfg->trace_offset, cfg->lde_offset, d_lde));
     mark(1);
-    for (uint32_t c = 0; c < W; c++) SMI_TRY(launch_merkle(ctx, d_lde + (size_t)c * N, N, trees[c]));
+    SMI_TRY(launch_merkle_batch(ctx, d_lde, N, tree_base, W, N, tree_stride));
     mark(2);
     HIP_TRY(ctx, hipMemcpyAsync(d_rootp, rootp.data(), sizeof(void *) * W, hipMemcpyHostToDevice, ctx->stream));
     fs_weights_kernel<<<1, 64, 0, ctx->stream>>>(d_rootp, W, d_weights);
