@@ -174,7 +174,7 @@ int smi_fri_fold(smi_ctx *ctx, const uint64_t *codeword, size_t len, uint64_t al
                  uint64_t omega, uint64_t *out);
 /* Fri::commit (src/fri.rs:105-156) with a fresh FiatShamir: roots gets R x 32 bytes, alphas
  * R-1 unreduced challenges, last_codeword domain_length >> (R-1) values.  *run (optional)
- * keeps codewords and trees on the device for smi_fri_query_run. */
+ * keeps every round's codeword and tree on the device (smi_fri_run_* accessors below). */
 int smi_fri_commit(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint64_t *codeword, size_t len, uint8_t *roots,
                    uint64_t *alphas, uint64_t *last_codeword, size_t *last_len, smi_fri_run **run);
 /* Fri::prove (src/fri.rs:250-311) with a fresh FiatShamir and ProofStream, returning
@@ -182,6 +182,11 @@ int smi_fri_commit(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint64_t *codewor
  * top_indices gets num_colinearity_tests entries (the method's return value). */
 int smi_fri_prove(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint64_t *codeword, size_t len, uint8_t **proof,
                   size_t *proof_len, uint64_t *top_indices);
+/* The `codewords` Fri::commit returns (src/fri.rs:153-155): their count, one of them (out may be
+ * NULL to query *len), and MerkleTree::open on a round's retained tree. */
+int smi_fri_run_num_codewords(const smi_fri_run *run, size_t *n);
+int smi_fri_run_codeword(smi_fri_run *run, size_t round, uint64_t *out, size_t *len);
+int smi_fri_run_open(smi_fri_run *run, size_t round, size_t index, uint8_t *path, size_t *depth);
 void smi_fri_run_free(smi_fri_run *run);
 void smi_free(void *p);
 

@@ -118,6 +118,9 @@ def lib():
         "smi_fri_fold": (i32, [vp, vp, sz, C.c_uint64, C.c_uint64, C.c_uint64, vp]),
         "smi_fri_commit": (i32, [vp, C.POINTER(FriCfg), vp, sz, vp, vp, vp, C.POINTER(sz), C.POINTER(vp)]),
         "smi_fri_prove": (i32, [vp, C.POINTER(FriCfg), vp, sz, C.POINTER(vp), C.POINTER(sz), vp]),
+        "smi_fri_run_num_codewords": (i32, [vp, C.POINTER(sz)]),
+        "smi_fri_run_codeword": (i32, [vp, sz, vp, C.POINTER(sz)]),
+        "smi_fri_run_open": (i32, [vp, sz, sz, vp, C.POINTER(sz)]),
         "smi_fri_run_free": (None, [vp]),
         "smi_free": (None, [vp]),
         "smi_dev_alloc": (i32, [vp, sz, C.POINTER(vp)]),

@@ -444,6 +444,27 @@ int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, si
 }
 
 // ------------------------------------------------------------------------- C ABI
+// Accessors of a retained commit: the `codewords` Fri::commit returns (src/fri.rs:153-155) and
+// MerkleTree::open on the per-round trees (src/fri.rs:297-298 rebuilds them; here they are kept).
+int smi_fri_run_num_codewords(const smi_fri_run *run, size_t *n) {
+    if (!run || !n) return SMI_ERR_BAD_ARG;
+    *n = run->codewords.size();
+    return SMI_OK;
+}
+int smi_fri_run_codeword(smi_fri_run *run, size_t round, uint64_t *out, size_t *len) {
+    if (!run || !len) return SMI_ERR_BAD_ARG;
+    if (round >= run->codewords.size()) return smi_fail(run->ctx, SMI_ERR_INDEX_OOB, nullptr);
+    *len = run->lens[round];
+    if (!out) return SMI_OK;
+    return smi_dev_download_u64(run->ctx, run->codewords[round], run->lens[round], out);
+}
+int smi_fri_run_open(smi_fri_run *run, size_t round, size_t index, uint8_t *path, size_t *depth) {
+    if (!run || !path || !depth) return SMI_ERR_BAD_ARG;
+    if (round >= run->trees.size()) return smi_fail(run->ctx, SMI_ERR_INDEX_OOB, nullptr);
+    smi_tree t{run->ctx, run->trees[round], (size_t)run->lens[round], false};
+    return smi_merkle_open(run->ctx, &t, index, path, depth);
+}
+
 int smi_dev_fri_fold(smi_ctx *ctx, const uint32_t *d_in, size_t len, const uint64_t *d_alpha, uint64_t offset,
                      uint64_t omega, uint32_t *d_out) {
     if (!ctx || !d_in || !d_alpha || !d_out) return SMI_ERR_BAD_ARG;

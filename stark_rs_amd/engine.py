@@ -217,6 +217,18 @@ class Engine:
                                        last.ctypes.data, C.byref(ll), None))
         return roots, [int(a) for a in alphas[:R - 1]], last[:ll.value].copy()
 
+    def fri_commit_run(self, cfg, codeword):
+        """Fri::commit keeping every round's codeword and tree on the device -> (roots, alphas, FriRun)."""
+        c = _u64(codeword)
+        R = max(self.fri_num_rounds(cfg), 1)
+        roots = np.zeros((R, 32), dtype=np.uint8)
+        alphas = np.zeros(R, dtype=np.uint64)
+        last = np.zeros(len(c), dtype=np.uint64)
+        ll, run = C.c_size_t(), vp()
+        self._ck(self.L.smi_fri_commit(self.h, C.byref(cfg), c.ctypes.data, len(c), roots.ctypes.data, alphas.ctypes.data,
+                                       last.ctypes.data, C.byref(ll), C.byref(run)))
+        return roots, [int(a) for a in alphas[:R - 1]], FriRun(self, run)
+
     def fri_prove(self, cfg, codeword):
         """-> (ProofStream::serialize bytes, top-level indices) -- Fri::prove, src/fri.rs:250-311."""
         c = _u64(codeword)
@@ -338,6 +350,42 @@ class DeviceTree:
     def free(self):
         if self.h:
             self.eng.L.smi_merkle_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class FriRun:
+    """Device-resident result of Fri::commit: the codewords it returns and the per-round trees."""
+
+    def __init__(self, eng, handle):
+        self.eng, self.h = eng, handle
+
+    def __len__(self):
+        n = C.c_size_t()
+        self.eng._ck(self.eng.L.smi_fri_run_num_codewords(self.h, C.byref(n)))
+        return n.value
+
+    def codeword(self, rnd):
+        ln = C.c_size_t()
+        self.eng._ck(self.eng.L.smi_fri_run_codeword(self.h, rnd, None, C.byref(ln)))
+        out = np.empty(ln.value, dtype=np.uint64)
+        self.eng._ck(self.eng.L.smi_fri_run_codeword(self.h, rnd, out.ctypes.data, C.byref(ln)))
+        return out
+
+    def open(self, rnd, index):
+        path = np.zeros((64, 32), dtype=np.uint8)
+        depth = C.c_size_t()
+        self.eng._ck(self.eng.L.smi_fri_run_open(self.h, rnd, index, path.ctypes.data, C.byref(depth)))
+        return [bytes(path[i]) for i in range(depth.value)]
+
+    def free(self):
+        if self.h:
+            self.eng.L.smi_fri_run_free(self.h)
             self.h = None
 
     def __del__(self):

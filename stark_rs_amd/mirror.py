@@ -444,17 +444,18 @@ class Fri:
                 for i in range(self.domain_length >> rnd)]
 
     def commit(self, initial_codeword, proof_stream, fiat_shamir):
-        """fri.rs:105-156.  Returns the codewords' final element (the last codeword); roots are
-        pushed to the proof stream and absorbed, like the reference."""
+        """fri.rs:105-156: pushes the roots and the last codeword, absorbs the roots, and returns
+        the codewords of every round (`Vec<Vec<FieldElement>>`), read back from the device."""
         if fiat_shamir.transcript:
             raise StarkMiError(-50, "bad argument: the device transcript starts empty (fresh FiatShamir)")
-        roots, alphas, last = self._eng.fri_commit(self._cfg, _vals(initial_codeword))
+        roots, alphas, run = self._eng.fri_commit_run(self._cfg, _vals(initial_codeword))
         for r in roots:
             proof_stream.push(ProofObject(0, Hash(bytes(r))))
             fiat_shamir.absorb(bytes(r))
-        last_fe = [FieldElement(int(v), self.field) for v in last]
-        proof_stream.push(ProofObject(2, last_fe))
-        return last_fe
+        codewords = [[FieldElement(int(v), self.field) for v in run.codeword(i)] for i in range(len(run))]
+        run.free()
+        proof_stream.push(ProofObject(2, list(codewords[-1])))
+        return codewords
 
     def prove(self, initial_codeword, fiat_shamir, proof_stream):
         """fri.rs:250-311: fills proof_stream, absorbs the roots into fiat_shamir, returns the

@@ -263,6 +263,29 @@ def test_fri_commit_trace_and_larger_prove(eng, oracle):
     assert o.fri_verify(ocfg, proof), o.fri_last_reject()
 
 
+def test_fri_commit_run_codewords_and_openings(eng, oracle):
+    """Fri::commit's returned codewords (fri.rs:153-155) and openings of the retained per-round trees."""
+    o = oracle
+    n, exp, t, offset = 1 << 10, 4, 4, 7
+    omega = o.ff_prim_nth_root(n)
+    codeword = o.fast_coset_ntt(_vals(o, 3, n // exp), n, omega, offset)
+    cfg, ocfg = eng.fri_cfg(omega, offset, n, exp, t), o.fri_cfg(omega, offset, n, exp, t)
+    roots, alphas, run = eng.fri_commit_run(cfg, codeword)
+    wroots, walphas, wlast = o.fri_commit_trace(ocfg, codeword)
+    assert np.array_equal(roots, wroots) and alphas == walphas and len(run) == len(wroots)
+    cw, w, off = codeword, omega, offset
+    for r in range(len(run)):
+        assert np.array_equal(run.codeword(r), cw)
+        nodes = o.merkle_new(o.leaf_hashes(cw))
+        for i in (0, len(cw) // 3, len(cw) - 1):
+            assert run.open(r, i) == o.merkle_open(nodes, len(cw), i)
+        if r + 1 < len(run):
+            cw = o.fri_fold_codeword(ocfg, cw, alphas[r], off, w)
+            w, off = o.ff_mul(w, w), o.ff_mul(off, off)
+    assert np.array_equal(run.codeword(len(run) - 1), wlast)
+    run.free()
+
+
 def test_fri_panics(eng, oracle):
     import stark_rs_amd as s
     o = oracle
