@@ -20,6 +20,9 @@ template <int OP> __global__ void k(uint32_t *out, uint32_t a0, uint32_t b0) {
             if (OP == 5) x[i] = (x[i] ^ b) + (x[i] >> 3);                                 // 3 simple ops
             if (OP == 6) { double d = (double)x[i]; d = fma(d, 1.0000001, 3.0); x[i] = (uint32_t)d; }       // f64 fma + cvts
             if (OP == 7) x[i] = __builtin_amdgcn_perm(x[i], b, 0x01020300u) + 1;          // v_perm_b32
+            if (OP == 8) { float f = __uint_as_float(x[i]); f = fmaf(f, 1.0000001f, 3.0f); f = fmaf(f, 0.9999f, 1.0f); x[i] = __float_as_uint(f); }  // 2 x v_fma_f32
+            if (OP == 9) { x[i] = (x[i] ^ b) & (x[i] >> 1); x[i] = (x[i] | b) ^ (x[i] << 2); }   // logic/shift mix (~6 ops)
+            if (OP == 10) { uint32_t t; asm volatile("v_add3_u32 %0, %1, %2, %3" : "=v"(t) : "v"(x[i]), "v"(b), "v"(x[(i + 1) & 7])); x[i] = t; asm volatile("v_xor_b32 %0, %1, %2" : "=v"(t) : "v"(x[i]), "v"(b)); x[i] = t; }
         }
     }
     uint32_t s = 0;
@@ -54,5 +57,8 @@ int main() {
     run<3>("v_mul_u32_u24 (+add)", 1);
     run<6>("cvt+f64 fma+cvt", 1);
     run<7>("v_perm_b32 (+add)", 1);
+    run<8>("2x v_fma_f32", 2);
+    run<9>("logic/shift mix", 6);
+    run<10>("add3 + xor (asm)", 2);
     return 0;
 }
