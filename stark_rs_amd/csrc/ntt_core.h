@@ -33,7 +33,7 @@
 #define SMI_TILE_LOG 12          // smallest tile (and the size limit of the single-workgroup kernel)
 #define SMI_TILE (1u << SMI_TILE_LOG)
 #define SMI_NTT_THREADS 256      // threads of the small kernel; pass kernels use tile/16 threads
-#define SMI_TW_LOG 10            // in-tile twiddle table: w_1024^j
+#define SMI_TW_LOG 11            // in-tile twiddle table: w_2048^j
 
 // A table twiddle in plain form with its Shoup quotient q = floor(w * 2^32 / p).
 struct alignas(8) Tw2 {
@@ -41,7 +41,7 @@ struct alignas(8) Tw2 {
 };
 
 struct NttTables {        // per (prime, direction)
-    const Tw2 *tw10;      // w_1024^j, j < 1024 (plain + Shoup quotient)
+    const Tw2 *tw10;      // w_2048^j, j < 2048 (plain + Shoup quotient)
     const uint32_t *lo;   // W^e,          e < 2^h      (Montgomery form; W = primitive 2^K-th root)
     const uint32_t *hi;   // W^(e * 2^h),  e < 2^(K-h)  (Montgomery form)
     uint32_t K, h;
@@ -82,6 +82,7 @@ template <> struct Steps<7>  { enum { n = 2, s0 = 4, s1 = 3, s2 = 0 }; };
 template <> struct Steps<8>  { enum { n = 2, s0 = 4, s1 = 4, s2 = 0 }; };
 template <> struct Steps<9>  { enum { n = 3, s0 = 4, s1 = 3, s2 = 2 }; };
 template <> struct Steps<10> { enum { n = 3, s0 = 4, s1 = 3, s2 = 3 }; };
+template <> struct Steps<11> { enum { n = 3, s0 = 4, s1 = 4, s2 = 3 }; };
 
 template <int S> SMI_HD constexpr uint32_t brev(uint32_t x) {
     uint32_t r = 0;

@@ -18,7 +18,8 @@ struct NttPlan {
 #define SMI_NTT_SHAPES(X) \
     X(6, 6) X(7, 5) X(8, 4) X(9, 3) X(10, 2) /* 4096-point tiles  */ \
     X(7, 6) X(8, 5) X(9, 4) X(10, 3)         /* 8192-point tiles  */ \
-    X(8, 6) X(9, 5) X(10, 4)                 /* 16384-point tiles */
+    X(8, 6) X(9, 5) X(10, 4) X(11, 3)        /* 16384-point tiles */ \
+    X(11, 2)                                 /* 8192-point tile, 2048-point lines */
 inline bool ntt_shape_ok(int lr, int lw) {
 #define X(a, b) if (lr == a && lw == b) return true;
     SMI_NTT_SHAPES(X)
@@ -65,7 +66,7 @@ inline NttPlan ntt_make_plan(uint32_t L, uint32_t batch = 1) {
         }
         if (ntt_plan_valid(L, o)) return o;
     }
-    pl.np = L <= 20 ? 2 : (L <= 30 ? 3 : 4);
+    pl.np = L <= 22 ? 2 : (L <= 30 ? 3 : 4);
     int rem = (int)L;
     for (int i = 0; i < pl.np; i++) {
         int left = pl.np - i;
@@ -95,7 +96,7 @@ inline NttPlan ntt_make_plan(uint32_t L, uint32_t batch = 1) {
 }
 
 // log2 of the radix of the last in-tile step for a digit of logr bits (Steps<logr> in ntt_core.h)
-inline int ntt_last_step_log(int logr) { return logr == 6 ? 2 : logr == 7 ? 3 : logr == 8 ? 4 : logr == 9 ? 2 : 3; }
+inline int ntt_last_step_log(int logr) { return logr == 6 ? 2 : logr == 7 ? 3 : logr == 8 ? 4 : logr == 9 ? 2 : 3; }  // 10, 11 -> 3
 
 // Geometric table entry (Montgomery form): c * q^(i*stride); q_m, c_m in Montgomery form.
 SMI_HD uint32_t geom_entry(uint32_t c_m, uint32_t q_m, uint64_t i, uint64_t stride, const Fp &F) {
