@@ -40,7 +40,7 @@ def main():
     for spec in sys.argv[1:]:
         f = spec.split(":")
         kind = f[0]
-        p = s.P2 if "p2" in f or (kind in ("ntt", "lde", "prove", "merkle", "fold") and int(f[1]) + (int(f[2]) if kind in ("lde", "prove") else 0) > 23) else s.P_REF
+        p = s.P2 if "p2" in f or (kind in ("ntt", "lde", "hostlde", "prove", "merkle", "fold") and int(f[1]) + (int(f[2]) if kind in ("lde", "hostlde", "prove") else 0) > 23) else s.P_REF
         e = eng_for(p)
         if kind == "ntt":
             L, batch, inv = int(f[1]), int(f[2]) if len(f) > 2 else 1, "inv" in f
@@ -60,6 +60,10 @@ def main():
             a = torch.tensor([0x0123456789ABCDEF], dtype=torch.int64, device="cuda")
             w = e.prim_nth_root(1 << L)
             run = lambda: e.dev_fri_fold(x.data_ptr(), 1 << L, a.data_ptr(), 3, w, y.data_ptr())
+        elif kind == "hostlde":   # host-buffer entry point: u64 in/out over PCIe (the drop-in call)
+            L, lb, W = int(f[1]), int(f[2]), int(f[3])
+            hx = np.random.default_rng(1).integers(0, p, (W, 1 << L), dtype=np.int64).astype(np.uint64)
+            run = lambda: e.lde(hx, lb, 1, 3)
         elif kind == "prove":
             L, lb, W = int(f[1]), int(f[2]), int(f[3])
             x = rnd(W << L, p)
