@@ -9,7 +9,7 @@ import re
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "build", "libstarkmi.so")
+LIB_PATH = os.environ.get("SMI_LIB") or os.path.join(_HERE, "build", "libstarkmi.so")   # SMI_LIB: tuning builds
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "stark_mi.h")
 
 u8p = C.POINTER(C.c_uint8)

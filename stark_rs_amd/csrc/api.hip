@@ -68,6 +68,8 @@ int smi_ctx_create(uint64_t p, uint64_t g, int device, smi_ctx **out) {
     int rc = SMI_OK;
     do {
         if (hipSetDevice(device) != hipSuccess) { rc = SMI_ERR_NO_DEVICE; break; }
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->num_cus = cus;
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { rc = SMI_ERR_HIP; break; }
         ctx->own_stream = true;
         if (hipMalloc((void **)&ctx->d_flag, sizeof(int)) != hipSuccess) { rc = SMI_ERR_OOM; break; }
@@ -97,7 +99,6 @@ void smi_ctx_destroy(smi_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (int d = 0; d < 2; d++)
         for (int k = 0; k < 3; k++) (void)hipFree(ctx->d_tab[d][k]);
-    for (PassTable &t : ctx->pass_tables) (void)hipFree(t.d);
     for (ScaleEntry &e : ctx->scale_cache) {
         (void)hipFree(e.lo);
         (void)hipFree(e.hi);

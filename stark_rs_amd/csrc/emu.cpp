@@ -23,8 +23,9 @@ std::vector<uint32_t> fill(const GeomSpec &s, const Fp &F) {
     return t;
 }
 
-template <int LOGR, int LOGW, bool LAST> void emu_pass(const PassArgs &a, uint32_t batch) {
-    typedef NttPass<LOGR, LOGW, LAST> NP;
+template <int LOGR, int LOGW, int KIND, int CAP> void emu_pass(const PassArgs &a, uint32_t batch) {
+    typedef NttPass<LOGR, LOGW, KIND, CAP> NP;
+    constexpr bool LAST = KIND == PASS_LAST;
     std::vector<uint32_t> tile(NP::R * NP::WP);
     std::vector<Tw2> tw(NP::R);
     for (uint32_t b = 0; b < batch; b++)
@@ -42,7 +43,11 @@ template <int LOGR, int LOGW, bool LAST> void emu_pass(const PassArgs &a, uint32
                 switch (a.zlog) { ZCASE(0) ZCASE(1) ZCASE(2) ZCASE(3) ZCASE(4) }
 #undef ZCASE
             } else {
-                for (uint32_t tid = 0; tid < NT; tid++) NP::load_lds(a, t, b, tile.data(), tid);
+                for (uint32_t tid = 0; tid < NT; tid++) {
+                    uint32_t v[16];
+                    NP::load_rows(a, t, b, v, tid);
+                    NP::rows_to_lds(v, tile.data(), tid);
+                }
                 for (uint32_t tid = 0; tid < NT; tid++) NP::step0_lds(a, tile.data(), tw.data(), tid);
             }
             for (uint32_t tid = 0; tid < NT; tid++) NP::step_mid(a, tile.data(), tw.data(), tid);
@@ -51,14 +56,6 @@ template <int LOGR, int LOGW, bool LAST> void emu_pass(const PassArgs &a, uint32
 }
 
 struct EmuLauncher {
-    Fp F;
-    NttTables T;
-    std::vector<std::vector<Tw2>> tabs;
-    const Tw2 *pass_table(uint32_t mlog, uint32_t logr) {
-        tabs.emplace_back((size_t)1 << mlog);
-        for (uint32_t i = 0; i < (1u << mlog); i++) tabs.back()[i] = pass_table_entry(i, mlog, logr, T, F);
-        return tabs.back().data();
-    }
     void small(const SmallArgs &a, uint32_t batch) {
         std::vector<uint32_t> buf(1u << a.L);
         for (uint32_t b = 0; b < batch; b++) {
@@ -71,8 +68,14 @@ struct EmuLauncher {
     void pass(int logr, int logw, bool last, const PassArgs &a, uint32_t batch) {
 #define X(LR, LW)                                           \
     if (logr == LR && logw == LW) {                         \
-        if (last) emu_pass<LR, LW, true>(a, batch);         \
-        else emu_pass<LR, LW, false>(a, batch);             \
+        const bool wide = a.F.p < (1u << 29);               \
+        const int kind = last ? PASS_LAST : (a.flags & NTT_FIRST) ? PASS_FIRST : PASS_MID;   \
+        if (wide && kind == PASS_FIRST) emu_pass<LR, LW, PASS_FIRST, 8>(a, batch);   \
+        else if (wide && kind == PASS_MID) emu_pass<LR, LW, PASS_MID, 8>(a, batch);  \
+        else if (wide) emu_pass<LR, LW, PASS_LAST, 8>(a, batch);                     \
+        else if (kind == PASS_FIRST) emu_pass<LR, LW, PASS_FIRST, 4>(a, batch);      \
+        else if (kind == PASS_MID) emu_pass<LR, LW, PASS_MID, 4>(a, batch);          \
+        else emu_pass<LR, LW, PASS_LAST, 4>(a, batch);                               \
         return;                                             \
     }
         SMI_NTT_SHAPES(X)
@@ -118,8 +121,6 @@ extern "C" int emu_ntt(uint64_t p, uint64_t g, const uint32_t *in, uint32_t *out
     rq.in = in; rq.out = out; rq.scratch = scratch.data();
     rq.L = L; rq.n_in = n_in; rq.batch = batch; rq.in_stride = in_stride; rq.out_stride = out_stride; rq.F = F;
     EmuLauncher ln;
-    ln.F = F;
-    ln.T = rq.T;
     ntt_run(ln, rq);
     return 0;
 }

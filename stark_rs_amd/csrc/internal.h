@@ -13,12 +13,6 @@ struct ScaleEntry {
     uint32_t *lo, *hi;
 };
 
-struct PassTable {   // cached inter-pass twiddle table (see tables.h pass_table_entry)
-    int inverse;
-    uint32_t mlog, logr;
-    Tw2 *d;
-};
-
 struct ProfRec {
     const char *name;
     hipEvent_t e0, e1;
@@ -27,12 +21,12 @@ struct ProfRec {
 
 struct smi_ctx {
     int device = 0;
+    int num_cus = 256;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     FieldSetup fs;
     uint32_t *d_tab[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};  // [dir][tw10, lo, hi]
     std::vector<ScaleEntry> scale_cache;
-    std::vector<PassTable> pass_tables;
     uint32_t *scratch = nullptr;   // NTT inter-pass buffer
     size_t scratch_elems = 0;
     void *tmp[4] = {nullptr, nullptr, nullptr, nullptr};  // staging buffers of the host-buffer entry points

@@ -8,28 +8,37 @@
 #include "ntt_driver.h"
 
 // ------------------------------------------------------------------------- kernels
-template <int LOGR, int LOGW, bool LAST>
+// One workgroup per (tile, column).  Tried and dropped (r01, measured on MI355X): persistent
+// workgroups that prefetch the next tile's loads into registers -- the extra live registers cost
+// more occupancy than the prefetch wins (2^25 x 4 middle pass 258 -> 290 us), and the hardware
+// dispatcher already staggers the load / compute / store phases of co-resident workgroups.
+template <int LOGR, int LOGW, int KIND, int CAP>
 __global__ __launch_bounds__(1 << (LOGR + LOGW - 4)) void ntt_pass_kernel(const PassArgs a) {
-    typedef NttPass<LOGR, LOGW, LAST> NP;
+    typedef NttPass<LOGR, LOGW, KIND, CAP> NP;
     __shared__ uint32_t tile[NP::R * NP::WP];
     __shared__ Tw2 tw[NP::R];
     const uint32_t tid = threadIdx.x, batch = blockIdx.y;
     const typename NP::TileId t = NP::tile_id(a, blockIdx.x);
     NP::load_tw(a, tw, tid);
-    if (!LAST) {
-        uint32_t v[NP::V];
+    uint32_t v[NP::V];
+    if constexpr (KIND == PASS_FIRST) {
         // zero-padded first passes (an LDE's blowup) skip the loads and the degenerate butterfly
         // stages of the padding; zlog is wave-uniform
-#define ZCASE(Z)                                       \
-    case Z:                                            \
+#define ZCASE(Z)                                         \
+    case Z:                                              \
         NP::template load_regs<Z>(a, t, batch, v, tid);  \
-        __syncthreads(); /* twiddle table staged */    \
+        __syncthreads(); /* twiddle table staged */      \
         NP::template step0_regs<Z>(a, v, tile, tw, tid); \
         break;
         switch (a.zlog) { ZCASE(2) ZCASE(3) ZCASE(4) default: ZCASE(0) }
 #undef ZCASE
+    } else if constexpr (KIND == PASS_MID) {
+        NP::template load_regs<0>(a, t, batch, v, tid);
+        __syncthreads();
+        NP::template step0_regs<0>(a, v, tile, tw, tid);
     } else {
-        NP::load_lds(a, t, batch, tile, tid);
+        NP::load_rows(a, t, batch, v, tid);
+        NP::rows_to_lds(v, tile, tid);
         __syncthreads();
         NP::step0_lds(a, tile, tw, tid);
     }
@@ -64,11 +73,6 @@ __global__ void geom_table_kernel(uint32_t *out, GeomSpec s, Fp F) {
     } else {
         out[i] = v;
     }
-}
-
-__global__ void pass_table_kernel(Tw2 *out, uint32_t mlog, uint32_t logr, NttTables T, Fp F) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < (1u << mlog)) out[i] = pass_table_entry(i, mlog, logr, T, F);
 }
 
 // u64 (reference wire width, src/stream.rs:45) <-> u32 device residues
@@ -122,38 +126,32 @@ struct HipLauncher {
         ntt_small_kernel<<<batch, SMI_NTT_THREADS, 0, ctx->stream>>>(a);
         note();
     }
+    template <int LR, int LW, int KIND, int CAP> void launch(const PassArgs &a) {
+        ntt_pass_kernel<LR, LW, KIND, CAP><<<dim3(a.n_tiles, a.batch), 1 << (LR + LW - 4), 0, ctx->stream>>>(a);
+    }
+    template <int LR, int LW, int CAP> void launch_kind(int kind, const PassArgs &a) {
+        if (kind == PASS_FIRST) launch<LR, LW, PASS_FIRST, CAP>(a);
+        else if (kind == PASS_MID) launch<LR, LW, PASS_MID, CAP>(a);
+        else launch<LR, LW, PASS_LAST, CAP>(a);
+    }
     void pass(int logr, int logw, bool last, const PassArgs &a, uint32_t batch) {
-        const dim3 grid(a.n_tiles, batch);
         // algorithmic bytes of one pass: every point read once and written once (4 B each);
         // the first pass of a zero-padded transform reads only its n_in real inputs
         const double n = (double)(1ull << a.L);
         const double bytes = ((a.flags & NTT_FIRST) ? 4.0 * a.n_in : 4.0 * n) * batch + 4.0 * n * batch;
+        const bool wide = a.F.p < (1u << 29);   // lazy range 8p instead of 4p (ntt_core.h)
+        const int kind = last ? PASS_LAST : (a.flags & NTT_FIRST) ? PASS_FIRST : PASS_MID;
 #define X(LR, LW)                                                                                              \
     if (logr == LR && logw == LW) {                                                                            \
         ProfScope ps(ctx, last ? "ntt_pass_kernel<" #LR "," #LW ",last>" : "ntt_pass_kernel<" #LR "," #LW ">", bytes); \
-        if (last) ntt_pass_kernel<LR, LW, true><<<grid, 1 << (LR + LW - 4), 0, ctx->stream>>>(a);              \
-        else ntt_pass_kernel<LR, LW, false><<<grid, 1 << (LR + LW - 4), 0, ctx->stream>>>(a);                  \
+        if (wide) launch_kind<LR, LW, 8>(kind, a);                                                             \
+        else launch_kind<LR, LW, 4>(kind, a);                                                                  \
         note();                                                                                                \
         return;                                                                                                \
     }
         SMI_NTT_SHAPES(X)
 #undef X
         if (err == hipSuccess) err = hipErrorInvalidValue;
-    }
-    int inverse = 0;
-    const Tw2 *pass_table(uint32_t mlog, uint32_t logr) {
-        for (const PassTable &t : ctx->pass_tables)
-            if (t.inverse == inverse && t.mlog == mlog && t.logr == logr) return t.d;
-        if (mlog > 20) return nullptr;  // keep tables L2-sized; larger passes use the running product
-        PassTable t{inverse, mlog, logr, nullptr};
-        if (hipMalloc((void **)&t.d, sizeof(Tw2) << mlog) != hipSuccess) {
-            (void)hipGetLastError();
-            return nullptr;
-        }
-        pass_table_kernel<<<((1u << mlog) + 255) / 256, 256, 0, ctx->stream>>>(t.d, mlog, logr, ctx_tables(ctx, inverse), ctx->fs.F);
-        note();
-        ctx->pass_tables.push_back(t);
-        return t.d;
     }
     void note() {
         hipError_t e = hipGetLastError();
@@ -199,7 +197,6 @@ int dev_ntt(smi_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint32_t log_n,
     }
     if (log_n > SMI_TILE_LOG) SMI_TRY(ctx_scratch(ctx, (size_t)batch << log_n, &rq.scratch));
     HipLauncher ln{ctx};
-    ln.inverse = inverse ? 1 : 0;
     ntt_run(ln, rq);
     if (ln.err != hipSuccess) return smi_hip_fail(ctx, ln.err, "ntt kernel launch");
     return SMI_OK;

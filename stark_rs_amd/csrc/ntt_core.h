@@ -20,15 +20,25 @@
 // their global loads and every pass stores straight from the last step's registers, so a
 // two-step tile crosses LDS once.
 //
-// Arithmetic inside a tile is lazy (Harvey): values live in [0, 2p), p < 2^30;
-//   add:  s = a + b,            min(s, s - 2p)                  -> [0, 2p)
-//   sub:  d = a - b + 2p in (0, 4p) goes straight into a twiddle multiply, or is folded back
+// Arithmetic inside a tile is lazy (Harvey), p < 2^30: a register holds a value < m*p with the
+// bound m tracked at compile time (see dft_regs);
+//   add:  a + b                                   bound m_a + m_b
+//   sub:  a - b + m_b*p                           bound m_a + m_b; usually feeds a twiddle multiply
 //   mul by a table twiddle (w, wq = floor(w 2^32 / p)):  a*w - hi(a*wq)*p  -> [0, 2p)  (Shoup)
+//   fold: min(x, x - 2p) or min(x, x - 4p), only where the next sum would pass 2^32
 // and results are made canonical once, at the store.  The reference's arithmetic is exact
 // (`% p` on u128, src/ff.rs:138-160), so canonical residues are bit-identical whatever the
 // intermediate representation.
 #pragma once
 #include "field.h"
+
+// The CPU emulator (tests) checks every claimed bound at run time; device code carries none.
+#if defined(SMI_EMU_CHECKS) && !defined(__HIP_DEVICE_COMPILE__)
+#include <assert.h>
+#define SMI_BOUND_CHECK(x, m, p) assert((m) <= 8 && (uint64_t)(x) < (uint64_t)((m) ? (m) : 1) * (p) && ((m) || (x) == 0))
+#else
+#define SMI_BOUND_CHECK(x, m, p) ((void)0)
+#endif
 
 #define SMI_TILE_LOG 12          // smallest tile (and the size limit of the single-workgroup kernel)
 #define SMI_TILE (1u << SMI_TILE_LOG)
@@ -67,7 +77,7 @@ struct PassArgs {
     uint32_t n_mid;    // digits strictly between first and last pass
     uint32_t mid_log[2];
     uint32_t n_tiles;  // grid.x
-    const Tw2 *ptab;        // inter-pass twiddles w_m^(k*b) at [k*B + b] for passes after the first (else null)
+    uint32_t batch;    // grid.y
     uint32_t pre_ratio_m;   // q^(T*B): step of the input coset scale between a thread's loads (Montgomery)
     uint32_t post_ratio_m;  // q^((R/r_last) << Sp): step of the output scale between a thread's stores (Montgomery)
     uint32_t post_bi_ratio_m;  // q^(r_last << Sp): step of the output scale between a thread's butterflies
@@ -112,22 +122,37 @@ SMI_HD void st32(uint32_t *base, uint32_t idx, uint32_t v) { *(uint32_t *)((char
 SMI_HD Tw2 ld_tw(const Tw2 *base, uint32_t idx) { return *(const Tw2 *)((const char *)base + (size_t)(uint32_t)(idx << 3)); }
 
 // ---- lazy arithmetic on [0, 2p), p < 2^30
-SMI_HD uint32_t lz_add(uint32_t a, uint32_t b, uint32_t p2) {
-    const uint32_t s = a + b;          // < 4p < 2^32
-    return umin32(s, s - p2);          // s - 2p wraps to a huge value exactly when s < 2p
-}
-SMI_HD uint32_t lz_fold(uint32_t d, uint32_t p2) { return umin32(d, d - p2); }   // [0,4p) -> [0,2p)
 SMI_HD uint32_t shoup_mul(uint32_t a, const Tw2 &c, uint32_t p) {               // any a < 2^32 -> [0,2p)
     return a * c.w - umulhi32(a, c.q) * p;
 }
 SMI_HD uint32_t lz_canon(uint32_t a, uint32_t p) { return umin32(a, a - p); }  // [0,2p) -> [0,p)
 
-// S-stage radix-2 DIF on 2^S registers, lazy; x[brev(k)] = X_k on return.  cw = w_R^j table in
-// LDS, croot_shift = LOGR - S so that w_r^j = cw[j << croot_shift].
+// ---- static range bookkeeping.  Every register carries a compile-time bound m: value < m*p.
+// Canonical loads have m = 1, Shoup products m = 2, a sum m_u + m_v, a twiddle-free difference
+// u - v + m_v*p likewise m_u + m_v.  A value is only folded back when the next butterfly would
+// leave [0, 2^32): CAP = 4 for any p < 2^30, CAP = 8 for p < 2^29 (kernels are instantiated for
+// both and the launcher picks by the modulus).  After full unrolling the m's are constants, so
+// the tests below cost nothing at run time; the CPU emulator evaluates them as ordinary ints.
+SMI_HD void lz_fold_m(uint32_t &x, int &m, uint32_t p) {
+    if (m > 4) { x = umin32(x, x - 4u * p); m = 4; }          // [0,8p) -> [0,4p)
+    else if (m > 2) { x = umin32(x, x - 2u * p); m = 2; }     // [0,4p) -> [0,2p)
+}
+SMI_HD void lz_fold_to2(uint32_t &x, int &m, uint32_t p) {
+    lz_fold_m(x, m, p);
+    lz_fold_m(x, m, p);
+}
+SMI_HD uint32_t lz_canon_m(uint32_t x, int m, uint32_t p) {   // any tracked value -> [0,p)
+    lz_fold_to2(x, m, p);
+    return m > 1 ? umin32(x, x - p) : x;
+}
+
+// S-stage radix-2 DIF on 2^S registers, lazy; x[brev(k)] = X_k on return, m[] updated.  cw = w_R^j
+// table in LDS, croot_shift = LOGR - S so that w_r^j = cw[j << croot_shift].
 // Z: in the first Z stages the upper input of every butterfly is known to be zero (zero-padded
 // transform), so the butterfly degenerates to copy + twiddle.
-template <int S, int Z = 0> SMI_HD void dft_regs(uint32_t (&x)[1 << S], const Tw2 *cw, int croot_shift, const Fp &F) {
-    const uint32_t p2 = 2u * F.p;
+template <int S, int CAP, int Z = 0>
+SMI_HD void dft_regs(uint32_t (&x)[1 << S], int (&m)[1 << S], const Tw2 *cw, int croot_shift, const Fp &F) {
+    const uint32_t p = F.p;
 #pragma unroll
     for (int s = 0; s < S; s++) {
         const int half = (1 << S) >> (s + 1);
@@ -137,13 +162,25 @@ template <int S, int Z = 0> SMI_HD void dft_regs(uint32_t (&x)[1 << S], const Tw
             const int j = i | half;
             const int e = (i & (half - 1)) << s;    // w_{2half}^pos = w_r^(pos << s)
             if (s < Z) {
-                x[j] = e ? shoup_mul(x[i], cw[e << croot_shift], F.p) : x[i];
+                x[j] = e ? shoup_mul(x[i], cw[e << croot_shift], p) : x[i];
+                m[j] = e ? 2 : m[i];
                 continue;
             }
+#pragma unroll
+            for (int t = 0; t < 3; t++)             // at most two folds are ever needed
+                if (m[i] + m[j] > CAP) {
+                    if (m[i] >= m[j]) lz_fold_m(x[i], m[i], p);
+                    else lz_fold_m(x[j], m[j], p);
+                }
             const uint32_t u = x[i], v = x[j];
-            x[i] = lz_add(u, v, p2);
-            const uint32_t d = u - v + p2;          // (0, 4p)
-            x[j] = e ? shoup_mul(d, cw[e << croot_shift], F.p) : lz_fold(d, p2);
+            const int ms = m[i] + m[j];
+            SMI_BOUND_CHECK(u, m[i], p);
+            SMI_BOUND_CHECK(v, m[j], p);
+            x[i] = u + v;                                   // < ms*p <= CAP*p < 2^32
+            const uint32_t d = u - v + (uint32_t)m[j] * p;  // (0, ms*p)
+            m[i] = ms;
+            if (e) { x[j] = shoup_mul(d, cw[e << croot_shift], p); m[j] = 2; }
+            else { x[j] = d; m[j] = ms; }
         }
     }
 }
@@ -152,8 +189,11 @@ template <int S, int Z = 0> SMI_HD void dft_regs(uint32_t (&x)[1 << S], const Tw
 //
 // Tile program (sync = workgroup barrier; the emulator runs each phase for every thread first):
 //   strided pass: load_tw, load_regs | sync | step0_regs | sync | [step_mid | sync] | last_step_store
-//   last pass:    load_tw, load_lds  | sync | step0_lds  | sync | [step_mid | sync] | last_step_store
-template <int LOGR, int LOGW, bool LAST> struct NttPass {
+//   last pass:    load_tw, load_rows, rows_to_lds | sync | step0_lds | sync | [step_mid | sync] | last_step_store
+enum { PASS_FIRST = 0, PASS_MID = 1, PASS_LAST = 2 };   // kernel kinds: first strided pass (zero padding, coset
+                                                         // scale), later strided passes, last pass (transposing)
+template <int LOGR, int LOGW, int KIND, int CAP> struct NttPass {
+    static constexpr bool FIRST = KIND == PASS_FIRST, MID = KIND == PASS_MID, LAST = KIND == PASS_LAST;
     enum { TILE_LOG = LOGR + LOGW, TILE = 1 << TILE_LOG, NT = TILE / 16, R = 1 << LOGR, W = 1 << LOGW, WP = W + 1, V = 16 };
     typedef Steps<LOGR> St;
     enum { SL = St::n == 2 ? St::s1 : St::s2, RL = 1 << SL };   // radix of the last step
@@ -209,7 +249,7 @@ template <int LOGR, int LOGW, bool LAST> struct NttPass {
         const uint32_t blog = a.L - a.Sp - LOGR;
         const uint32_t w = tid & (W - 1), j0 = tid >> LOGW;
         const uint32_t o0 = (j0 << blog) + w;
-        if (a.flags & NTT_FIRST) {
+        if constexpr (FIRST) {
             // zero padding: in_base == b0 in the first pass, so b0 + o is the natural index.
             // Branch-free (clamped address + select) so the loads issue back to back.
             const uint32_t *col = a.in + (uint64_t)batch * a.in_stride;
@@ -241,26 +281,33 @@ template <int LOGR, int LOGW, bool LAST> struct NttPass {
     template <int Z> static SMI_HD void step0_regs(const PassArgs &a, uint32_t (&x)[V], uint32_t *tile, const Tw2 *tw, uint32_t tid) {
         enum { SUB = LOGR - 4 };
         const uint32_t w = tid & (W - 1), pos = tid >> LOGW;
-        dft_regs<4, Z>(x, tw, LOGR - 4, a.F);
+        int m[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) m[i] = i < (V >> Z) ? 1 : 0;   // canonical loads / scaled products; padding
+        dft_regs<4, CAP, Z>(x, m, tw, LOGR - 4, a.F);
 #pragma unroll
         for (int kk = 0; kk < 16; kk++) {
             uint32_t v = x[brev<4>(kk)];
+            int mv = m[brev<4>(kk)];
             if (kk) v = shoup_mul(v, tw[(pos * kk) & (R - 1)], a.F.p);
-            tile[(pos + ((uint32_t)kk << SUB)) * WP + w] = v;
+            else lz_fold_to2(v, mv, a.F.p);
+            tile[(pos + ((uint32_t)kk << SUB)) * WP + w] = v;       // LDS holds [0,2p)
         }
     }
 
-    // ---- last pass: rows are contiguous in HBM; load coalesced along the row, transpose via LDS
-    static SMI_HD void load_lds(const PassArgs &a, const TileId &t, uint32_t batch, uint32_t *tile, uint32_t tid) {
+    // ---- last pass: rows are contiguous in HBM; load coalesced along the row, transpose via LDS.
+    // Two phases (global -> registers, registers -> LDS): all 16 loads are in flight together.
+    static SMI_HD void load_rows(const PassArgs &a, const TileId &t, uint32_t batch, uint32_t (&v)[V], uint32_t tid) {
         const uint32_t *in = a.in + (uint64_t)batch * a.in_stride + t.in_base;
         const uint32_t arest_log = a.Sp - a.d0_log;
-        uint32_t v[V];
 #pragma unroll
         for (int i = 0; i < V; i++) {
             const uint32_t idx = tid + i * NT;
             const uint32_t j = idx & (R - 1), l = idx >> LOGR;
             v[i] = ld32(in, (l << (arest_log + LOGR)) + j);
         }
+    }
+    static SMI_HD void rows_to_lds(const uint32_t (&v)[V], uint32_t *tile, uint32_t tid) {
 #pragma unroll
         for (int i = 0; i < V; i++) {
             const uint32_t idx = tid + i * NT;
@@ -268,8 +315,8 @@ template <int LOGR, int LOGW, bool LAST> struct NttPass {
         }
     }
 
-    // One radix-2^S step LDS -> LDS on sub-blocks of 2^MLOG points (never the last step).
-    template <int S, int MLOG> static SMI_HD void step(const PassArgs &a, uint32_t *tile, const Tw2 *tw, uint32_t tid) {
+    // MIN: bound of the values read (1 = canonical, straight from a global load; 2 = earlier step).
+    template <int S, int MLOG, int MIN> static SMI_HD void step(const PassArgs &a, uint32_t *tile, const Tw2 *tw, uint32_t tid) {
         enum { r = 1 << S, SUB = MLOG - S, NB = (TILE / r) / NT };
 #pragma unroll
         for (int bi = 0; bi < NB; bi++) {
@@ -280,19 +327,24 @@ template <int LOGR, int LOGW, bool LAST> struct NttPass {
             uint32_t x[r];
 #pragma unroll
             for (int q = 0; q < r; q++) x[q] = tile[(base + ((uint32_t)q << SUB)) * WP + w];
-            dft_regs<S>(x, tw, LOGR - S, a.F);
+            int m[r];
+#pragma unroll
+            for (int q = 0; q < r; q++) m[q] = MIN;
+            dft_regs<S, CAP>(x, m, tw, LOGR - S, a.F);
 #pragma unroll
             for (int kk = 0; kk < r; kk++) {
                 uint32_t v = x[brev<S>(kk)];
+                int mv = m[brev<S>(kk)];
                 if (kk) v = shoup_mul(v, tw[((pos * kk) << (LOGR - MLOG)) & (R - 1)], a.F.p);
+                else lz_fold_to2(v, mv, a.F.p);
                 tile[(base + ((uint32_t)kk << SUB)) * WP + w] = v;
             }
         }
     }
-    static SMI_HD void step0_lds(const PassArgs &a, uint32_t *tile, const Tw2 *tw, uint32_t tid) { step<4, LOGR>(a, tile, tw, tid); }
+    static SMI_HD void step0_lds(const PassArgs &a, uint32_t *tile, const Tw2 *tw, uint32_t tid) { step<4, LOGR, 1>(a, tile, tw, tid); }
     // the middle step of a three-step tile (no-op for two-step tiles)
     static SMI_HD void step_mid(const PassArgs &a, uint32_t *tile, const Tw2 *tw, uint32_t tid) {
-        if constexpr (St::n == 3) step<St::s1, LOGR - St::s0>(a, tile, tw, tid);
+        if constexpr (St::n == 3) step<St::s1, LOGR - St::s0, 2>(a, tile, tw, tid);
     }
 
     // position of a last-step block (all digits but the last) -> its weight in the frequency index
@@ -315,7 +367,7 @@ template <int LOGR, int LOGW, bool LAST> struct NttPass {
         // lookups per thread whatever NB is.
         uint32_t base_run = 0, gs = 0, gq = 0, gbi = 0, gbq = 0;   // first pass: g^kbase, g^(R/RL), g^RL
         uint32_t sc_run = 0, rq = 0, rbq = 0;                        // last pass: scale(kn_base) and ratios
-        if (!LAST && !a.ptab) {
+        if constexpr (!LAST) {
             const uint32_t b = t.b0 + (tid & (W - 1)), sh = a.T.K - mlog;
             base_run = two_level(a.T.lo, a.T.hi, a.T.h, (b * blk_to_k(tid >> LOGW)) << sh, a.F);
             gs = two_level(a.T.lo, a.T.hi, a.T.h, (b << KSTEP_LOG) << sh, a.F);
@@ -337,23 +389,19 @@ template <int LOGR, int LOGW, bool LAST> struct NttPass {
             uint32_t x[RL];
 #pragma unroll
             for (int q = 0; q < RL; q++) x[q] = tile[(blk * RL + q) * WP + w];
-            dft_regs<SL>(x, tw, LOGR - SL, a.F);
+            int m[RL];
+#pragma unroll
+            for (int q = 0; q < RL; q++) m[q] = 2;
+            dft_regs<SL, CAP>(x, m, tw, LOGR - SL, a.F);   // outputs < CAP*p: fine for any multiply below
             const uint32_t kbase = blk_to_k(blk);
-            if (!LAST) {
+            if constexpr (!LAST) {
                 const uint32_t blog = mlog - LOGR;
                 const uint32_t o0 = (kbase << blog) + w;
-                if (a.ptab) {
-                    // passes after the first: w_m^(k*b) from this pass's (L2-resident) table, read
-                    // with the data's own coalescing
-                    const Tw2 *tab = a.ptab + t.b0;
-#pragma unroll
-                    for (int kk = 0; kk < RL; kk++) {
-                        const uint32_t o = o0 + ((uint32_t)kk << (KSTEP_LOG + blog));
-                        st32(out, o, lz_canon(shoup_mul(x[brev<SL>(kk)], ld_tw(tab, o), p), p));
-                    }
-                } else {
-                    // first pass (m = n: a table would double the traffic): w_m^(k*b) = g^k, g = w_m^b;
-                    // running products over kk (and over the thread's butterflies, see above)
+                {
+                    // inter-pass twiddles w_m^(k*b) = g^k, g = w_m^b: running products over kk (and over
+                    // the thread's butterflies, see above).  A per-pass table of (w, Shoup quotient)
+                    // pairs read with the data's coalescing saves 60 VALU ops per thread but triples
+                    // the L2 -> L1 traffic of the pass; measured slower (2^25 x 4: 266 vs 247 us).
                     uint32_t cur = base_run;
                     if (bi + 1 < NB) base_run = mont_mul_c(base_run, gbi, gbq, a.F);
 #pragma unroll
@@ -374,7 +422,7 @@ template <int LOGR, int LOGW, bool LAST> struct NttPass {
                     }
                 } else {
 #pragma unroll
-                    for (int kk = 0; kk < RL; kk++) st32(out, o0 + ((uint32_t)kk << (KSTEP_LOG + a.Sp)), lz_canon(x[brev<SL>(kk)], p));
+                    for (int kk = 0; kk < RL; kk++) st32(out, o0 + ((uint32_t)kk << (KSTEP_LOG + a.Sp)), lz_canon_m(x[brev<SL>(kk)], m[brev<SL>(kk)], p));
                 }
             }
         }

@@ -23,7 +23,6 @@ struct NttRequest {
 // Launcher concept:
 //   void small(const SmallArgs&, uint32_t batch);
 //   void pass(int logr, int logw, bool last, const PassArgs&, uint32_t batch);
-//   const Tw2 *pass_table(uint32_t mlog, uint32_t logr);   // w_m^(k*b) table (cached), or nullptr
 template <class Launcher> inline void ntt_run(Launcher &ln, const NttRequest &rq) {
     const NttPlan pl = ntt_make_plan(rq.L, rq.batch);
     if (pl.np == 0) {
@@ -52,7 +51,7 @@ template <class Launcher> inline void ntt_run(Launcher &ln, const NttRequest &rq
         a.n_mid = (uint32_t)(pl.np - 2);
         for (int d = 0; d < pl.np - 2; d++) a.mid_log[d] = (uint32_t)pl.logr[1 + d];
         a.n_tiles = (uint32_t)(n >> (pl.logr[p] + pl.logw[p]));
-        a.ptab = (!first && !last) ? ln.pass_table(rq.L - consumed, (uint32_t)pl.logr[p]) : nullptr;
+        a.batch = rq.batch;
         {   // steps of the running-product scales (see NttPass::load / store)
             const uint32_t logw = (uint32_t)pl.logw[p], blog = rq.L - consumed - (uint32_t)pl.logr[p];
             const uint64_t pre_step = (uint64_t)((1u << (pl.logr[p] + pl.logw[p] - 4)) >> logw) << blog;

@@ -62,11 +62,3 @@ SMI_HD Tw2 tw2_from_mont(uint32_t v_m, const Fp &F) {
     const uint32_t w = from_mont(v_m, F);
     return Tw2{w, (uint32_t)(((uint64_t)w << 32) / F.p)};
 }
-
-// Inter-pass twiddle table of one pass: entry [k*B + b] = w_m^(k*b), m = 2^mlog = R*B (Tw2 pairs).
-SMI_HD Tw2 pass_table_entry(uint32_t idx, uint32_t mlog, uint32_t logr, const NttTables &T, const Fp &F) {
-    const uint32_t blog = mlog - logr, k = idx >> blog, b = idx & ((1u << blog) - 1u);
-    const uint32_t e = (k * b) << (T.K - mlog);
-    const uint32_t v = e ? two_level(T.lo, T.hi, T.h, e, F) : F.r1;
-    return tw2_from_mont(v, F);
-}
