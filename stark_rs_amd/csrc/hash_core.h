@@ -6,12 +6,10 @@
 //     (bit 8 of 502*b is the rotated-out bit), src/hash.rs:88-94;
 //   * the 4-byte linear mix (src/hash.rs:64-75) is plain XORs of whole words: groups g and
 //     g+4 share words 4g..4g+3;
-//   * the sequential in-place ring add (src/hash.rs:77-81), which is a prefix sum mod 256:
-//        new[i] = P[i] + P[i+1] + old[31] - old[0]   (i <= 30),  P[i] = sum_{j<=i} old[j]
-//        new[31] = old[31] + new[0] + new[30]
-//     becomes a 15-add running sum over the words (lane sums stay < 2^16, so the two bytes
-//     of a word never interfere), with the round constants (src/hash.rs:83-85,96-99)
-//     folded into the per-word constants J_w.
+//   * the sequential in-place ring add (src/hash.rs:77-81) runs on both lanes at once, one
+//     three-input add per word, once the two lane crossings have been resolved from the byte
+//     sum of lane 0 (see mix_t); lane sums stay < 2^16, so the two bytes of a word never
+//     interfere.  The round constants (src/hash.rs:83-85,96-99) ride in the next S-box's addend.
 // Everything is integer/byte work: VALU-bound, no LDS, no MFMA.
 #pragma once
 #include <stdint.h>
@@ -93,6 +91,22 @@ SMI_HD uint32_t add3(uint32_t a, uint32_t b, uint32_t c) {
 #endif
 }
 
+// The high 16-bit lane copied into both lanes (v_perm_b32), and {hi:lo} >> 16 (v_alignbit_b32).
+SMI_HD uint32_t dup_hi16(uint32_t a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(a, a, 0x03020302u);
+#else
+    return (a >> 16) * 0x00010001u;
+#endif
+}
+SMI_HD uint32_t funnel16(uint32_t hi, uint32_t lo) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, 16);
+#else
+    return (lo >> 16) | (hi << 16);
+#endif
+}
+
 // State convention: the TRUE state byte is (stored lane + pending round constant) mod 256, where
 // the round constants of the previous mix (src/hash.rs:83-85) may still be pending; only the low 8
 // bits of a lane are meaningful (bits 8..15 may hold carry dirt below 2^16).
@@ -137,20 +151,26 @@ template <bool PENDING> SMI_HD void mix_t(State &st) {
         s[4 * q + 2] = (T ^ t3) & 0x00FF00FFu;
         s[4 * q + 3] = (T ^ t0) & 0x00FF00FFu;
     }
-    // (3) ring add as a prefix sum (round constants stay pending)
-    const uint32_t old0 = s[0] & 0xFFFFu, old16 = s[0] >> 16, old31 = s[15] >> 16;
-    const uint32_t c = old31 + 256u - old0;  // old[31] - old[0] mod 256, positive
-    uint32_t S[16];
-    S[0] = s[0];
+    // (3) ring add (src/hash.rs:77-81), round constants stay pending.  With a_w = byte w (lane 0) and
+    // b_w = byte 16+w (lane 1) the sequential in-place recurrence is lane-parallel for words 1..14:
+    //     N[w] = N[w-1] + s[w] + s[w+1]                                  (one v_add3 per word)
+    // and the two places where the lanes meet are closed up front from A = sum_w a_w:
+    //     new[15] = a_15 + b_0 + new[14] = 2A - a_0 + b_0 + b_15   (unrolling new[1..14])
+    //     N[0]  = (a_0 + a_1 + b_15) | (b_0 + b_1 + new[15]) << 16
+    //     N[15] = N[14] + s[15] + (b_0 | new[0] << 16)
+    // Lane 0 never exceeds 16*2*255 + 765 < 2^16, so it cannot carry into lane 1; lane 1 may wrap
+    // out of the top of the word (only the low 8 bits of a lane are meaningful afterwards).
+    const uint32_t t1 = add3(s[0], s[1], s[2]), t2 = add3(s[3], s[4], s[5]), t3 = add3(s[6], s[7], s[8]);
+    const uint32_t t4 = add3(s[9], s[10], s[11]), t5 = add3(s[12], s[13], s[14]);
+    const uint32_t tot = add3(t1, t2, t3) + add3(t4, t5, s[15]);   // lane 0: A (< 4096)
+    const uint32_t m0 = s[0] * 0xFFFF0001u;                         // lane 0: a_0, lane 1: b_0 - a_0
+    uint32_t N[16];
+    N[0] = add3((tot << 17) + m0, s[1], dup_hi16(s[15])) + (s[0] & 0xFFFF0000u);
 #pragma unroll
-    for (int w = 1; w < 16; w++) S[w] = S[w - 1] + s[w];       // lane0: P[w]; lane1: P[16+w] - P[15]
-    const uint32_t p15 = S[15] & 0xFFFFu;
-    const uint32_t E = c * 0x00010001u + (p15 << 17);          // lane0: c; lane1: c + 2*P[15]
+    for (int w = 1; w < 15; w++) N[w] = add3(N[w - 1], s[w], s[w + 1]);
+    N[15] = add3(N[14], s[15], funnel16(N[0], s[0]));               // + (b_0 | new[0] << 16)
 #pragma unroll
-    for (int w = 0; w < 15; w++) s[w] = add3(S[w], S[w + 1], E);  // new[w] | new[16+w]   (lanes < 2^15)
-    const uint32_t lo = 2u * p15 + old16 + c;                   // new[15] = P[15] + P[16] + c
-    const uint32_t hi = old31 + (s[0] & 0xFFFFu) + (s[14] >> 16);  // new[31] = old[31] + new[0] + new[30]
-    s[15] = lo | (hi << 16);
+    for (int w = 0; w < 16; w++) s[w] = N[w];
 }
 
 // One complete mix_state on a fully applied state (used by the single-lane transcript kernels).
