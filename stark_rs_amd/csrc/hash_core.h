@@ -107,6 +107,30 @@ SMI_HD uint32_t funnel16(uint32_t hi, uint32_t lo) {
 #endif
 }
 
+// {hi:lo} >> 8 bits*n for n in 1..3 (v_alignbit_b32), and the byte permute of {hi:lo}
+// (v_perm_b32): selector byte 0..3 picks a byte of lo, 4..7 a byte of hi, 0x0C gives 0x00.
+SMI_HD uint32_t funnel(uint32_t hi, uint32_t lo, int bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, bits);
+#else
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> bits);
+#endif
+}
+SMI_HD uint32_t perm8(uint32_t hi, uint32_t lo, uint32_t sel) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+    const uint64_t v = ((uint64_t)hi << 32) | lo;
+    uint32_t r = 0;
+    for (int k = 0; k < 4; k++) {
+        const uint32_t c = (sel >> (8 * k)) & 0xFFu;
+        const uint32_t b = c < 8 ? (uint32_t)(v >> (8 * c)) & 0xFFu : (c == 0x0Cu ? 0u : 0xFFu);
+        r |= b << (8 * k);
+    }
+    return r;
+#endif
+}
+
 // State convention: the TRUE state byte is (stored lane + pending round constant) mod 256, where
 // the round constants of the previous mix (src/hash.rs:83-85) may still be pending; only the low 8
 // bits of a lane are meaningful (bits 8..15 may hold carry dirt below 2^16).
@@ -195,36 +219,91 @@ SMI_HD void absorb_byte(State &st, int pos, uint32_t byte) {
     xor_byte(st, (pos + 7) & 31, v);
 }
 
-// digest as 8 little-endian u32 words (bytes 4j..4j+3 in d[j])
+// ---- "natural" layout: 8 little-endian words, bytes 4j..4j+3 in P[j] -- the layout of a digest and
+// of a message chunk.  Whole 32-byte chunks are absorbed in it, four bytes per op.
+
+// paired lanes -> natural; only the low byte of each lane is read, so carry dirt is ignored
 SMI_HD void to_words(const State &st, uint32_t d[8]) {
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        const int w = (j & 3) * 4, sh = (j & 4) ? 16 : 0;
-        d[j] = ((st.s[w] >> sh) & 0xFFu) | (((st.s[w + 1] >> sh) & 0xFFu) << 8) | (((st.s[w + 2] >> sh) & 0xFFu) << 16) |
-               (((st.s[w + 3] >> sh) & 0xFFu) << 24);
+        const int w = (j & 3) * 4;
+        const uint32_t k = (j & 4) ? 2u : 0u;   // byte of the lane inside its word
+        const uint32_t lo = perm8(st.s[w + 1], st.s[w], 0x0C0C0000u | ((4u + k) << 8) | k);
+        const uint32_t hi = perm8(st.s[w + 3], st.s[w + 2], 0x00000C0Cu | ((4u + k) << 24) | (k << 16));
+        d[j] = lo | hi;
     }
 }
-
-// absorb one full 32-byte chunk given as 8 LE words, then mix (src/hash.rs:14-23)
-SMI_HD void absorb_chunk32(State &st, const uint32_t m[8]) {
+// natural -> paired lanes (clean)
+SMI_HD void from_words(const uint32_t P[8], State &st) {
 #pragma unroll
-    for (int i = 0; i < 32; i++) absorb_byte(st, i, (m[i >> 2] >> (8 * (i & 3))) & 0xFFu);
-    mix(st);
+    for (int w = 0; w < 16; w++) {
+        const uint32_t k = (uint32_t)w & 3u;
+        st.s[w] = perm8(P[(w >> 2) + 4], P[w >> 2], 0x0C000C00u | ((4u + k) << 16) | k);
+    }
 }
-// same, leaving the round constants of the mix pending (callers continue with mix_t<true>)
-SMI_HD void absorb_chunk32_pending(State &st, const uint32_t m[8]) {
+SMI_HD uint32_t add_bytes(uint32_t a, uint32_t b) {   // four independent sums mod 256
+    return ((a & 0x7F7F7F7Fu) + (b & 0x7F7F7F7Fu)) ^ ((a ^ b) & 0x80808080u);
+}
+SMI_HD uint32_t rotl3_bytes(uint32_t x) { return bfi32(0xF8F8F8F8u, x << 3, x >> 5); }
+
+// src/hash.rs:15-20 for one full chunk.  With v_i the value byte i takes when it is processed,
+//     v_i = rotl3(s_i + m_i)               (i < 7)
+//     v_i = rotl3((s_i ^ v_{i-7}) + m_i)   (i >= 7: the XOR from byte i-7 arrived earlier)
+// and afterwards bytes 0..6 receive the XORs of bytes 25..31.  Byte i depends on byte i-7 only, so
+// the four bytes of a word are independent and word j needs words j-2 and j-1.
+SMI_HD void absorb32_words(uint32_t P[8], const uint32_t M[8]) {
+    uint32_t V[8];
 #pragma unroll
-    for (int i = 0; i < 32; i++) absorb_byte(st, i, (m[i >> 2] >> (8 * (i & 3))) & 0xFFu);
-    mix_t<false>(st);
+    for (int j = 0; j < 8; j++) {
+        uint32_t x = P[j];
+        if (j == 1) x ^= V[0] << 24;
+        if (j >= 2) x ^= funnel(V[j - 1], V[j - 2], 8);   // v_{4j-7} .. v_{4j-4}
+        V[j] = rotl3_bytes(add_bytes(x, M[j]));
+    }
+    V[0] ^= funnel(V[7], V[6], 8);   // bytes 0..3 ^= v_25..v_28
+    V[1] ^= V[7] >> 8;               // bytes 4..6 ^= v_29..v_31
+#pragma unroll
+    for (int j = 0; j < 8; j++) P[j] = V[j];
+}
+
+// initial state in natural layout (src/hash.rs:10-12)
+struct InitWords {
+    uint32_t p[8];
+};
+constexpr InitWords make_init_words() {
+    const uint8_t pr[16] = SMI_PRIMES;
+    InitWords w{};
+    for (int j = 0; j < 8; j++)
+        for (int k = 0; k < 4; k++) w.p[j] |= (uint32_t)pr[(4 * j + k) % 16] << (8 * k);
+    return w;
+}
+
+// absorb one full 32-byte chunk given as 8 LE words, then mix (src/hash.rs:14-23); the state
+// must be fully applied (no pending round constants)
+SMI_HD void absorb_chunk32(State &st, const uint32_t m[8]) {
+    uint32_t P[8];
+    to_words(st, P);
+    absorb32_words(P, m);
+    from_words(P, st);
+    mix(st);
 }
 
 // Hash::from_field_elements(&[v as u64]) (src/hash.rs:32-35 as used by src/fri.rs:118-121):
 // 8 message bytes (LE u64 of a u32 residue: the upper four are zero), 1 + 8 mixes.
 SMI_HD void leaf_hash(uint32_t v, uint32_t d[8]) {
-    State st;
-    init(st);
+    constexpr InitWords I = make_init_words();
+    uint32_t P[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) absorb_byte(st, i, i < 4 ? ((v >> (8 * i)) & 0xFFu) : 0u);
+    for (int j = 0; j < 8; j++) P[j] = I.p[j];
+    // the 8-byte chunk touches bytes 0..14: v_0..v_7 as above (m_4..m_7 = 0), bytes 8..14 ^= v_1..v_7
+    const uint32_t V0 = rotl3_bytes(add_bytes(P[0], v));
+    const uint32_t V1 = rotl3_bytes(P[1] ^ (V0 << 24));
+    P[0] = V0;
+    P[1] = V1;
+    P[2] ^= funnel(V1, V0, 8);
+    P[3] ^= V1 >> 8;
+    State st;
+    from_words(P, st);
     mix_t<false>(st);
 #pragma unroll 1
     for (int k = 0; k < 8; k++) mix_t<true>(st);
@@ -234,10 +313,18 @@ SMI_HD void leaf_hash(uint32_t v, uint32_t d[8]) {
 
 // Hash::combine (src/hash.rs:41-46): 64 bytes = two chunks, 2 + 8 mixes.
 SMI_HD void node_hash(const uint32_t l[8], const uint32_t r[8], uint32_t d[8]) {
+    constexpr InitWords I = make_init_words();
+    uint32_t P[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) P[j] = I.p[j];
+    absorb32_words(P, l);
     State st;
-    init(st);
-    absorb_chunk32(st, l);
-    absorb_chunk32_pending(st, r);
+    from_words(P, st);
+    mix(st);
+    to_words(st, P);
+    absorb32_words(P, r);
+    from_words(P, st);
+    mix_t<false>(st);
 #pragma unroll 1
     for (int k = 0; k < 8; k++) mix_t<true>(st);
     flush(st);
