@@ -65,6 +65,60 @@ __global__ __launch_bounds__(SMI_HASH_THREADS) void merkle_sub_kernel(const uint
     }
 }
 
+// The top of a tree: one workgroup takes a level of at most SMI_TOP_MAX digests (or that many
+// codeword elements) and builds every level above it, a barrier per level, the current level
+// held in LDS as [word][slot].  These levels are pure latency (one node hash deep each, a few
+// wavefronts wide): as separate launches they cost ~6.5 us per level, here one hash latency.
+#define SMI_TOP_MAX 2048
+#define SMI_TOP_THREADS (SMI_TOP_MAX / 2)
+template <bool FROM_ELEMS>
+__global__ __launch_bounds__(SMI_TOP_THREADS) void merkle_top_kernel(const uint32_t *__restrict__ elems, uint4 *nodes, size_t n,
+                                                                      uint32_t lvl_in, uint32_t count_in, size_t elem_stride,
+                                                                      size_t node_stride) {
+    __shared__ uint32_t buf[8 * SMI_TOP_MAX];
+    elems += (size_t)blockIdx.x * elem_stride;
+    nodes += (size_t)blockIdx.x * node_stride;
+    const uint32_t tid = threadIdx.x;
+    uint32_t d[8];
+    for (uint32_t i = tid; i < count_in; i += SMI_TOP_THREADS) {
+        if (FROM_ELEMS) {
+            hashc::leaf_hash(elems[i], d);
+            nodes[2 * (size_t)i] = make_uint4(d[0], d[1], d[2], d[3]);
+            nodes[2 * (size_t)i + 1] = make_uint4(d[4], d[5], d[6], d[7]);
+        } else {
+            const uint4 *src = nodes + 2 * (level_offset(n, lvl_in) + i);
+            const uint4 a = src[0], b = src[1];
+            d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+        }
+#pragma unroll
+        for (int w = 0; w < 8; w++) buf[w * SMI_TOP_MAX + i] = d[w];
+    }
+    __syncthreads();
+    uint32_t lvl = lvl_in;
+    for (uint32_t cnt = count_in; cnt > 1; cnt >>= 1) {   // cnt, lvl are workgroup-uniform
+        const uint32_t half = cnt >> 1;
+        lvl++;
+        if (tid < half) {
+            uint32_t l[8], r[8];
+#pragma unroll
+            for (int w = 0; w < 8; w++) {
+                l[w] = buf[w * SMI_TOP_MAX + 2 * tid];
+                r[w] = buf[w * SMI_TOP_MAX + 2 * tid + 1];
+            }
+            hashc::node_hash(l, r, d);
+            uint4 *dst = nodes + 2 * (level_offset(n, lvl) + tid);
+            dst[0] = make_uint4(d[0], d[1], d[2], d[3]);
+            dst[1] = make_uint4(d[4], d[5], d[6], d[7]);
+        }
+        __syncthreads();   // every pair of this level has been read
+        if (tid < half) {
+#pragma unroll
+            for (int w = 0; w < 8; w++) buf[w * SMI_TOP_MAX + tid] = d[w];
+        }
+        __syncthreads();
+    }
+}
+
 // digests only (Hash::from_field_elements per element)
 __global__ __launch_bounds__(SMI_HASH_THREADS) void leaf_hash_kernel(const uint32_t *__restrict__ elems, uint4 *out, size_t n) {
     const size_t i = (size_t)blockIdx.x * SMI_HASH_THREADS + threadIdx.x;
@@ -184,6 +238,16 @@ int launch_merkle_batch(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t
         return SMI_OK;
     }
     while (lvl < depth || from_elems) {
+        if (count <= SMI_TOP_MAX) {   // the rest of the tree in one launch per tree
+            const double hashed = from_elems ? 2.0 * (double)count - 1.0 : (double)count - 1.0;
+            ProfScope ps(ctx, "merkle_top_kernel", ((from_elems ? 4.0 : 32.0) * (double)count + 32.0 * hashed) * n_trees);
+            if (from_elems)
+                merkle_top_kernel<true><<<n_trees, SMI_TOP_THREADS, 0, ctx->stream>>>(d_elems, nodes, n, 0, (uint32_t)count, elem_stride, node_stride);
+            else
+                merkle_top_kernel<false><<<n_trees, SMI_TOP_THREADS, 0, ctx->stream>>>(nullptr, nodes, n, lvl, (uint32_t)count, 0, node_stride);
+            HIP_TRY(ctx, hipGetLastError());
+            return SMI_OK;
+        }
         uint32_t K = depth - lvl < KMAX ? depth - lvl : KMAX;
         const size_t threads = count >> K;
         const size_t lds = (size_t)(8u << K) * SMI_HASH_THREADS * sizeof(uint32_t);
