@@ -62,11 +62,24 @@ SMI_HD uint32_t pk_mad_u16(uint32_t a, uint32_t m, uint32_t c) {
 #endif
 }
 
-// (mask & a) | (~mask & b) and a + b + c as single VALU ops (the compiler otherwise splits them).
+// A constant held in a VGPR.  On gfx950 the simple VALU ops (add, sub, and, or, xor, right shifts,
+// v_bitop3) issue in 2 cycles per wave only while every source is a VGPR or an inline constant; with
+// an SGPR or literal source they take 4 like the multiplies and the other three-operand ops
+// (measured, tools/ubench_valu.hip).  The empty asm is pure, so it is hoisted out of the mix loops.
+SMI_HD uint32_t vreg(uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SMI_NO_VREG)   // SMI_NO_VREG: tuning builds only
+    asm("" : "+v"(c));
+#endif
+    return c;
+}
+
+// (mask & a) | (~mask & b) and a ^ b ^ c as single VALU ops (the compiler otherwise splits them).
 SMI_HD uint32_t bfi32(uint32_t mask, uint32_t a, uint32_t b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     uint32_t r;
-    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(mask), "v"(a), "v"(b));
+    // as a three-input bit op (table 0xCA = (m & a) | (~m & b)): v_bitop3_b32 issues at twice the
+    // rate of v_bfi_b32 on gfx950 (tools/ubench_valu.hip)
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xca" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
     return r;
 #else
     return (mask & a) | (~mask & b);
@@ -81,15 +94,9 @@ SMI_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
     return a ^ b ^ c;
 #endif
 }
-SMI_HD uint32_t add3(uint32_t a, uint32_t b, uint32_t c) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t r;
-    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-#else
-    return a + b + c;
-#endif
-}
+// v_add3_u32 costs what two v_add_u32 cost (4 cycles per wave either way), so the choice is left
+// to the compiler: it keeps s[w] + s[w+1] off the dependent chain of the ring add.
+SMI_HD uint32_t add3(uint32_t a, uint32_t b, uint32_t c) { return a + (b + c); }
 
 // The high 16-bit lane copied into both lanes (v_perm_b32), and {hi:lo} >> 16 (v_alignbit_b32).
 SMI_HD uint32_t dup_hi16(uint32_t a) {
@@ -158,22 +165,23 @@ template <bool PENDING> SMI_HD void mix_t(State &st) {
     uint32_t *s = st.s;
     // (1) S-box  rotl1(251*b) (^0x63 deferred): t = 502*(b + rc); result = (t & 0xFE) | bit 8 of t.
     // Bits 8..15 of the result lanes are left dirty; the linear layer's last XOR masks them.
+    const uint32_t kFE = vreg(0x00FE00FEu), kFF = vreg(0x00FF00FFu), k63 = vreg(0x00630063u), kHI = vreg(0xFFFF0000u);
     uint32_t r[16];
 #pragma unroll
     for (int w = 0; w < 16; w++) {
         const uint32_t t = pk_mad_u16(s[w], 0x01F601F6u, PENDING ? C.rc502[w] : 0u);
-        r[w] = bfi32(0x00FE00FEu, t, t >> 8);
+        r[w] = bfi32(kFE, t, t >> 8);
     }
     // (2) linear mix: new = (t0^t1^t2^t3) ^ {t2, t1, t3, t0}, with the deferred ^0x63 (it passes
     // through the three-byte XORs unchanged); the final XOR also masks the lanes clean.
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const uint32_t t0 = r[4 * q], t1 = r[4 * q + 1], t2 = r[4 * q + 2], t3 = r[4 * q + 3];
-        const uint32_t T = xor3(xor3(t0, t1, t2), t3, 0x00630063u);
-        s[4 * q] = (T ^ t2) & 0x00FF00FFu;
-        s[4 * q + 1] = (T ^ t1) & 0x00FF00FFu;
-        s[4 * q + 2] = (T ^ t3) & 0x00FF00FFu;
-        s[4 * q + 3] = (T ^ t0) & 0x00FF00FFu;
+        const uint32_t T = xor3(xor3(t0, t1, t2), t3, k63);
+        s[4 * q] = (T ^ t2) & kFF;
+        s[4 * q + 1] = (T ^ t1) & kFF;
+        s[4 * q + 2] = (T ^ t3) & kFF;
+        s[4 * q + 3] = (T ^ t0) & kFF;
     }
     // (3) ring add (src/hash.rs:77-81), round constants stay pending.  With a_w = byte w (lane 0) and
     // b_w = byte 16+w (lane 1) the sequential in-place recurrence is lane-parallel for words 1..14:
@@ -189,7 +197,7 @@ template <bool PENDING> SMI_HD void mix_t(State &st) {
     const uint32_t tot = add3(t1, t2, t3) + add3(t4, t5, s[15]);   // lane 0: A (< 4096)
     const uint32_t m0 = s[0] * 0xFFFF0001u;                         // lane 0: a_0, lane 1: b_0 - a_0
     uint32_t N[16];
-    N[0] = add3((tot << 17) + m0, s[1], dup_hi16(s[15])) + (s[0] & 0xFFFF0000u);
+    N[0] = add3((tot << 17) + m0, s[1], dup_hi16(s[15])) + (s[0] & kHI);
 #pragma unroll
     for (int w = 1; w < 15; w++) N[w] = add3(N[w - 1], s[w], s[w + 1]);
     N[15] = add3(N[14], s[15], funnel16(N[0], s[0]));               // + (b_0 | new[0] << 16)
@@ -242,9 +250,10 @@ SMI_HD void from_words(const uint32_t P[8], State &st) {
     }
 }
 SMI_HD uint32_t add_bytes(uint32_t a, uint32_t b) {   // four independent sums mod 256
-    return ((a & 0x7F7F7F7Fu) + (b & 0x7F7F7F7Fu)) ^ ((a ^ b) & 0x80808080u);
+    const uint32_t k7F = vreg(0x7F7F7F7Fu), k80 = vreg(0x80808080u);
+    return ((a & k7F) + (b & k7F)) ^ ((a ^ b) & k80);
 }
-SMI_HD uint32_t rotl3_bytes(uint32_t x) { return bfi32(0xF8F8F8F8u, x << 3, x >> 5); }
+SMI_HD uint32_t rotl3_bytes(uint32_t x) { return bfi32(vreg(0xF8F8F8F8u), x << 3, x >> 5); }
 
 // src/hash.rs:15-20 for one full chunk.  With v_i the value byte i takes when it is processed,
 //     v_i = rotl3(s_i + m_i)               (i < 7)
