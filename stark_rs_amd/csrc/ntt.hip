@@ -143,7 +143,7 @@ struct HipLauncher {
         const int kind = last ? PASS_LAST : (a.flags & NTT_FIRST) ? PASS_FIRST : PASS_MID;
 #define X(LR, LW)                                                                                              \
     if (logr == LR && logw == LW) {                                                                            \
-        ProfScope ps(ctx, last ? "ntt_pass_kernel<" #LR "," #LW ",last>" : "ntt_pass_kernel<" #LR "," #LW ">", bytes); \
+        ProfScope ps(ctx, kind == PASS_LAST ? "ntt_pass_kernel<" #LR "," #LW ",last>" : kind == PASS_MID ? "ntt_pass_kernel<" #LR "," #LW ",mid>" : "ntt_pass_kernel<" #LR "," #LW ",first>", bytes); \
         if (wide) launch_kind<LR, LW, 8>(kind, a);                                                             \
         else launch_kind<LR, LW, 4>(kind, a);                                                                  \
         note();                                                                                                \

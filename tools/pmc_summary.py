@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Development tool: condense the rocprofv3 outputs of tools/profile.sh into the small files kept
+under profiles/ (kernel stats CSVs, PMC traffic per launch, the bench line of the stats run).
+
+HBM traffic per launch = FETCH_SIZE * 2 + WRITE_SIZE (both reported in KB): on gfx950 FETCH_SIZE
+tallies 128-byte requests at 64 bytes (MI355X_MICROARCH.md, "HBM"), WRITE_SIZE is exact for
+streaming stores."""
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
+KIND = {"0": "first", "1": "mid", "2": "last"}
+
+
+def bench_name(sym):
+    """rocprofv3 kernel symbol -> the name bench.py / smi_ctx_profile use."""
+    m = re.search(r"ntt_pass_kernel<(\d+), (\d+), (\d+), \d+>", sym)
+    if m:
+        return f"ntt_pass_kernel<{m.group(1)},{m.group(2)},{KIND[m.group(3)]}>"
+    m = re.search(r"merkle_sub_kernel<(true|false)>", sym)
+    if m:
+        return "merkle_sub_kernel<leaves>" if m.group(1) == "true" else "merkle_sub_kernel<digests>"
+    m = re.search(r"(\w+_kernel)", sym)
+    return m.group(1) if m else sym
+
+
+def counters(run_dir):
+    """{bench kernel name: {counter: [values per dispatch]}}"""
+    out = {}
+    for path in glob.glob(os.path.join(run_dir, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(path)):
+            k = bench_name(row["Kernel_Name"])
+            out.setdefault(k, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+    return out
+
+
+def main():
+    src, tag = sys.argv[1], sys.argv[2]
+    dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    os.makedirs(dst, exist_ok=True)
+    for sub, name in (("stats", "lde"), ("prove", "prove")):
+        for path in glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True):
+            shutil.copy(path, os.path.join(dst, f"{tag}_{name}_kernel_stats.csv"))
+    fetch, write, valu = counters(os.path.join(src, "fetch")), counters(os.path.join(src, "write")), counters(os.path.join(src, "valu"))
+    summary = {}
+    for k in sorted(set(fetch) | set(write)):
+        if not k.startswith("ntt_pass_kernel"):
+            continue
+        f = fetch.get(k, {}).get("FETCH_SIZE", [])
+        w = write.get(k, {}).get("WRITE_SIZE", [])
+        e = {"launches_profiled": len(f)}
+        if f and w:
+            e["FETCH_SIZE_KB_avg"] = sum(f) / len(f)
+            e["WRITE_SIZE_KB_avg"] = sum(w) / len(w)
+            e["hbm_bytes_per_launch"] = (2.0 * e["FETCH_SIZE_KB_avg"] + e["WRITE_SIZE_KB_avg"]) * 1024.0
+        v = valu.get(k, {})
+        if v.get("SQ_INSTS_VALU") and v.get("SQ_WAVES"):
+            e["valu_insts_per_wave"] = sum(v["SQ_INSTS_VALU"]) / sum(v["SQ_WAVES"])
+        summary[k] = e
+    note = ("rocprofv3 --pmc in separate passes (FETCH_SIZE | WRITE_SIZE | SQ_INSTS_VALU SQ_WAVES) over "
+            "`bench.py --no-extras --steps 20`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B "
+            "requests at 64 B); KB units; averages over all launches of the kernel in the run")
+    json.dump({"note": note, **summary}, open(os.path.join(dst, f"{tag}_lde_pmc.json"), "w"), indent=1)
+    json.dump(summary, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+    bj = os.path.join(src, "bench_stats.json")
+    if os.path.exists(bj):
+        lines = [l for l in open(bj) if l.startswith("{")]
+        if lines:
+            open(os.path.join(dst, f"{tag}_bench_under_rocprof.json"), "w").write(lines[-1])
+    print(json.dumps(summary, indent=1))
+
+
+if __name__ == "__main__":
+    main()
