@@ -115,10 +115,25 @@ SMI_HD uint32_t two_level(const uint32_t *lo, const uint32_t *hi, uint32_t h, ui
 // Global accesses as wave-uniform base + 32-bit byte offset (all tile-relative offsets stay below
 // 2^30 elements): lets the compiler use the SGPR-base addressing form instead of a 64-bit
 // vector add per access.
+#ifndef SMI_NTT_NT
+#define SMI_NTT_NT 0   // 1: tuning builds (non-temporal data loads and stores)
+#endif
 SMI_HD uint32_t ld32(const uint32_t *base, uint32_t idx) {
-    return *(const uint32_t *)((const char *)base + (size_t)(uint32_t)(idx << 2));
+    const uint32_t *p = (const uint32_t *)((const char *)base + (size_t)(uint32_t)(idx << 2));
+#if defined(__HIP_DEVICE_COMPILE__) && SMI_NTT_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
 }
-SMI_HD void st32(uint32_t *base, uint32_t idx, uint32_t v) { *(uint32_t *)((char *)base + (size_t)(uint32_t)(idx << 2)) = v; }
+SMI_HD void st32(uint32_t *base, uint32_t idx, uint32_t v) {
+    uint32_t *p = (uint32_t *)((char *)base + (size_t)(uint32_t)(idx << 2));
+#if defined(__HIP_DEVICE_COMPILE__) && SMI_NTT_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 SMI_HD Tw2 ld_tw(const Tw2 *base, uint32_t idx) { return *(const Tw2 *)((const char *)base + (size_t)(uint32_t)(idx << 3)); }
 
 // ---- lazy arithmetic on [0, 2p), p < 2^30

@@ -101,3 +101,23 @@ def test_emulated_ntt_explicit_tile_shapes(emu, oracle, L, plan):
         assert np.array_equal(_ntt(emu, P, G, vals[: n // 8], L, n // 8, 0, 3), o.fast_coset_ntt(vals[: n // 8], n, w, 3))
     finally:
         del os.environ[f"SMI_NTT_PLAN_{L}"]
+
+
+@pytest.mark.parametrize("p,g", [(P, G), (P2, G2)])
+@pytest.mark.parametrize("L", [13, 16, 18])
+def test_emulated_ntt_extreme_values_stay_in_range(emu, oracle, p, g, L):
+    """The lazy butterflies track a static bound m*p per register (ntt_core.h) and fold only where
+    the next sum would pass 2^32.  Constant and alternating inputs of p-1 drive every sum path to
+    its bound; the emulator build asserts each claimed bound (SMI_EMU_CHECKS) and the result must
+    still be the oracle's."""
+    o = oracle
+    n = 1 << L
+    w = o.ff_prim_nth_root_g(n, p, g)
+    pats = [np.full(n, p - 1, dtype=np.uint64),
+            np.where(np.arange(n) % 2 == 0, p - 1, 0).astype(np.uint64),
+            np.where((np.arange(n) >> 4) % 2 == 0, p - 1, 1).astype(np.uint64)]
+    for vals in pats:
+        assert np.array_equal(_ntt(emu, p, g, vals, L, n, 0, 1), o.fast_coset_ntt(vals, n, w, 1, p))   # no coset scale
+        assert np.array_equal(_ntt(emu, p, g, vals, L, n, 1, 1), o.fast_intt(vals, w, 1, p))
+        nin = n // 8
+        assert np.array_equal(_ntt(emu, p, g, vals[:nin], L, nin, 0, 3), o.fast_coset_ntt(vals[:nin], n, w, 3, p))

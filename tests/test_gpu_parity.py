@@ -109,6 +109,25 @@ def test_second_prime_sizes_above_2p23(eng2, oracle):
         assert np.array_equal(eng2.coset_ntt(vals[: n // 8], logn, 31), o.fast_coset_ntt(vals[: n // 8], n, w, 31, P2))
 
 
+@pytest.mark.parametrize("which", ["ref", "p2"])
+@pytest.mark.parametrize("logn", [14, 20, 22])
+def test_ntt_extreme_values_lazy_ranges(eng, eng2, oracle, which, logn):
+    """Constant / alternating inputs of p-1 push every sum path of the lazy butterflies to the
+    static bound the kernels track (4p for the reference prime, 8p for p < 2^29): a missed fold
+    would wrap mod 2^32 and show up here."""
+    o = oracle
+    e, p, g = (eng, P, G) if which == "ref" else (eng2, P2, G2)
+    n = 1 << logn
+    w = o.ff_prim_nth_root_g(n, p, g)
+    pats = [np.full(n, p - 1, dtype=np.uint64),
+            np.where(np.arange(n) % 2 == 0, p - 1, 0).astype(np.uint64),
+            np.where((np.arange(n) >> 4) % 2 == 0, p - 1, 1).astype(np.uint64)]
+    for vals in pats:
+        assert np.array_equal(e.coset_ntt(vals, logn, 1), o.fast_coset_ntt(vals, n, w, 1, p))
+        assert np.array_equal(e.intt(vals, 1), o.fast_intt(vals, w, 1, p))
+        assert np.array_equal(e.coset_ntt(vals[: n // 8], logn, 3), o.fast_coset_ntt(vals[: n // 8], n, w, 3, p))
+
+
 def test_poly_scale(eng, oracle):
     o = oracle
     assert list(eng.poly_scale([1, 2, 3], 2)) == [1, 4, 12]          # mod.rs:439-456
