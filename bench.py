@@ -9,7 +9,8 @@ that trace: 4 inverse NTTs of 2^22 points + 4 coset NTTs of 2^25 points.  Column
 units, so ranks share no data-path collective (weak scaling); value = NTT points transformed by
 all ranks per second.  Reported beside it in the same JSON line:
   * roofline    -- the dominant kernel's achieved HBM GB/s from HIP events around every launch
-                   in the timed region (algorithmic bytes: 8 B per point per pass, DESIGN.md);
+                   in the timed region (algorithmic bytes: 8 B per point per pass), and
+                   the same launch as a pure copy with the pass's access pattern (pattern_copy);
   * cpu_baseline-- the op-for-op CPU oracle of the reference path on a bounded sample (rank 0);
   * prove_ms    -- end-to-end build-defined prove (LDE + 4 column commits + combine + Fri::prove)
                    of the same trace, with per-stage HIP-event times;
@@ -148,6 +149,16 @@ def main():
             traffic = json.load(open(pmc_path)).get(dom_name, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    # What HBM delivers for each pass's own access pattern: the copy-only twin of every pass kernel
+    # (same tiles, loads and store addresses, no arithmetic), timed the same way.
+    eng.copy_probe(True)
+    eng.profile(True)
+    for _ in range(5):
+        step()
+    probes = eng.profile_read()
+    eng.profile(False)
+    eng.copy_probe(False)
+    probe_ms = {k.replace("ntt_copy_probe", "ntt_pass_kernel"): v["total_ms"] / v["launches"] for k, v in probes.items()}
     ntt_ms = sum(k["total_ms"] for k in kernels.values()) / args.steps
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -155,8 +166,12 @@ def main():
                 # whole-LDE view: SURVEY 8(d) (12+4B)*n*4 cols algorithmic bytes over the step's kernel time
                 "step_alg_bytes": (12 + 4 * (1 << LOG_BLOWUP)) * n * N_COLS,
                 "step_achieved": (12 + 4 * (1 << LOG_BLOWUP)) * n * N_COLS / (ntt_ms * 1e-3) / 1e9,
+                # the same launch as a pure copy (no arithmetic): the ceiling of this access pattern
+                "pattern_copy_GBps": (bytes_per_launch / (probe_ms[dom_name] * 1e-3) / 1e9) if dom_name in probe_ms else None,
+                "frac_of_pattern_copy": (probe_ms[dom_name] / avg_ms) if dom_name in probe_ms else None,
                 "kernels": {k: {"launches": v["launches"], "avg_ms": v["total_ms"] / v["launches"],
-                                "GBps": v["alg_bytes"] / (v["total_ms"] * 1e-3) / 1e9} for k, v in kernels.items()}}
+                                "GBps": v["alg_bytes"] / (v["total_ms"] * 1e-3) / 1e9,
+                                "copy_only_ms": probe_ms.get(k)} for k, v in kernels.items()}}
 
     result = {
         "metric": "ntt_field_elements_per_sec", "value": value, "unit": "field-elements/s",
@@ -266,6 +281,22 @@ def main():
             tt = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             result["sharded_fri_commit_2p25_ms"] = 1e3 * float(tt.item())
+            # ... and the whole Fri::prove over it (owners open their leaves, rank 0 serializes)
+            from stark_rs_amd.sharded import ShardedFriProve
+            fp = ShardedFriProve(be, p, eng.prim_nth_root(1 << logN), s.G2, 1 << logN, 1 << LOG_BLOWUP, N_TESTS, rank, world)
+            fp.prove(block)
+            torch.cuda.synchronize()
+            barrier()
+            t1 = time.perf_counter()
+            proof, _top = fp.prove(block)
+            torch.cuda.synchronize()
+            barrier()
+            dt = time.perf_counter() - t1
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            result["sharded_fri_prove_2p25_ms"] = 1e3 * float(tt.item())
+            if rank == 0:
+                result["sharded_fri_prove_bytes"] = len(proof)
           except Exception as e:
             result["sharded_fri_commit_error"] = str(e)
 

@@ -90,6 +90,11 @@ typedef struct {
 } smi_kernel_time;
 int smi_ctx_profile(smi_ctx *ctx, int enable);
 int smi_ctx_profile_read(smi_ctx *ctx, smi_kernel_time *out, size_t cap, size_t *n);
+/* Measurement aid for the roofline leg: while enabled, every NTT pass launches its copy-only twin
+ * (same tiles, same global loads and store addresses, no arithmetic) so that smi_ctx_profile
+ * times what HBM delivers for each pass's access pattern.  Outputs are meaningless while it is
+ * on; never enable it in product use. */
+int smi_ctx_copy_probe(smi_ctx *ctx, int enable);
 uint64_t smi_ctx_modulus(const smi_ctx *ctx);
 uint32_t smi_ctx_two_adicity(const smi_ctx *ctx);
 

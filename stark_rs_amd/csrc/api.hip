@@ -130,6 +130,11 @@ int smi_ctx_profile(smi_ctx *ctx, int enable) {
     ctx->prof_on = enable != 0;
     return SMI_OK;
 }
+int smi_ctx_copy_probe(smi_ctx *ctx, int enable) {
+    if (!ctx) return SMI_ERR_BAD_ARG;
+    ctx->copy_probe = enable != 0;
+    return SMI_OK;
+}
 int smi_ctx_profile_read(smi_ctx *ctx, smi_kernel_time *out, size_t cap, size_t *n) {
     if (!ctx || !n || (cap && !out)) return SMI_ERR_BAD_ARG;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

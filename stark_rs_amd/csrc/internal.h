@@ -34,6 +34,7 @@ struct smi_ctx {
     int *d_flag = nullptr;         // non-canonical input flag
     std::string err;
     bool prof_on = false;
+    bool copy_probe = false;       // smi_ctx_copy_probe: NTT passes launch their copy-only twins
     std::vector<ProfRec> prof;
     // bump arena for the per-prove device buffers (trees, folded codewords, proof bytes):
     // steady state does no hipMalloc/hipFree.  Overflow allocations are tracked and the

@@ -50,6 +50,39 @@ __global__ __launch_bounds__(1 << (LOGR + LOGW - 4)) void ntt_pass_kernel(const 
     NP::last_step_store(a, t, batch, tile, tw, tid);
 }
 
+// Measurement aid (smi_ctx_copy_probe): the same tile, the same global loads and the same store
+// addresses as ntt_pass_kernel, no arithmetic and no LDS -- what HBM delivers for this pass's
+// access pattern.  bench.py reports a pass's time against it beside the 8 TB/s peak.
+template <int LOGR, int LOGW, int KIND>
+__global__ __launch_bounds__(1 << (LOGR + LOGW - 4)) void ntt_copy_probe_kernel(const PassArgs a) {
+    typedef NttPass<LOGR, LOGW, KIND, 4> NP;
+    enum { NB = (NP::TILE / NP::RL) / NP::NT, KSTEP_LOG = LOGR - NP::SL };
+    const uint32_t tid = threadIdx.x, batch = blockIdx.y;
+    const typename NP::TileId t = NP::tile_id(a, blockIdx.x);
+    uint32_t v[NP::V];
+    if constexpr (KIND == PASS_LAST) {
+        NP::load_rows(a, t, batch, v, tid);
+    } else if constexpr (KIND == PASS_MID) {
+        NP::template load_regs<0>(a, t, batch, v, tid);
+    } else {
+        switch (a.zlog) {
+        case 2: NP::template load_regs<2>(a, t, batch, v, tid); break;
+        case 3: NP::template load_regs<3>(a, t, batch, v, tid); break;
+        case 4: NP::template load_regs<4>(a, t, batch, v, tid); break;
+        default: NP::template load_regs<0>(a, t, batch, v, tid); break;
+        }
+    }
+    uint32_t *out = a.out + (uint64_t)batch * a.out_stride + t.out_base;
+    const uint32_t sh = KIND == PASS_LAST ? a.Sp : a.L - a.Sp - LOGR;   // stride of the frequency index in the output
+#pragma unroll
+    for (int bi = 0; bi < NB; bi++) {
+        const uint32_t u = tid + bi * NP::NT;
+        const uint32_t o0 = (NP::blk_to_k(u >> LOGW) << sh) + (u & (NP::W - 1));
+#pragma unroll
+        for (int kk = 0; kk < NP::RL; kk++) st32(out, o0 + ((uint32_t)kk << (KSTEP_LOG + sh)), v[bi * NP::RL + kk] + 1u);
+    }
+}
+
 __global__ __launch_bounds__(SMI_NTT_THREADS) void ntt_small_kernel(const SmallArgs a) {
     __shared__ uint32_t buf[SMI_TILE];
     const uint32_t tid = threadIdx.x, batch = blockIdx.x;
@@ -129,6 +162,12 @@ struct HipLauncher {
     template <int LR, int LW, int KIND, int CAP> void launch(const PassArgs &a) {
         ntt_pass_kernel<LR, LW, KIND, CAP><<<dim3(a.n_tiles, a.batch), 1 << (LR + LW - 4), 0, ctx->stream>>>(a);
     }
+    template <int LR, int LW> void launch_probe(int kind, const PassArgs &a) {
+        const dim3 grid(a.n_tiles, a.batch);
+        if (kind == PASS_FIRST) ntt_copy_probe_kernel<LR, LW, PASS_FIRST><<<grid, 1 << (LR + LW - 4), 0, ctx->stream>>>(a);
+        else if (kind == PASS_MID) ntt_copy_probe_kernel<LR, LW, PASS_MID><<<grid, 1 << (LR + LW - 4), 0, ctx->stream>>>(a);
+        else ntt_copy_probe_kernel<LR, LW, PASS_LAST><<<grid, 1 << (LR + LW - 4), 0, ctx->stream>>>(a);
+    }
     template <int LR, int LW, int CAP> void launch_kind(int kind, const PassArgs &a) {
         if (kind == PASS_FIRST) launch<LR, LW, PASS_FIRST, CAP>(a);
         else if (kind == PASS_MID) launch<LR, LW, PASS_MID, CAP>(a);
@@ -143,6 +182,12 @@ struct HipLauncher {
         const int kind = last ? PASS_LAST : (a.flags & NTT_FIRST) ? PASS_FIRST : PASS_MID;
 #define X(LR, LW)                                                                                              \
     if (logr == LR && logw == LW) {                                                                            \
+        if (ctx->copy_probe) {                                                                                 \
+            ProfScope ps(ctx, kind == PASS_LAST ? "ntt_copy_probe<" #LR "," #LW ",last>" : kind == PASS_MID ? "ntt_copy_probe<" #LR "," #LW ",mid>" : "ntt_copy_probe<" #LR "," #LW ",first>", bytes); \
+            launch_probe<LR, LW>(kind, a);                                                                     \
+            note();                                                                                            \
+            return;                                                                                            \
+        }                                                                                                      \
         ProfScope ps(ctx, kind == PASS_LAST ? "ntt_pass_kernel<" #LR "," #LW ",last>" : kind == PASS_MID ? "ntt_pass_kernel<" #LR "," #LW ",mid>" : "ntt_pass_kernel<" #LR "," #LW ",first>", bytes); \
         if (wide) launch_kind<LR, LW, 8>(kind, a);                                                             \
         else launch_kind<LR, LW, 4>(kind, a);                                                                  \

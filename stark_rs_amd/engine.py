@@ -57,6 +57,11 @@ class Engine:
         """Bracket every hot-path kernel launch with HIP events on the context's stream."""
         self._ck(self.L.smi_ctx_profile(self.h, 1 if enable else 0))
 
+    def copy_probe(self, enable=True):
+        """Measurement aid: NTT passes launch their copy-only twins (same access pattern, no
+        arithmetic); results are meaningless while it is on."""
+        self._ck(self.L.smi_ctx_copy_probe(self.h, 1 if enable else 0))
+
     def profile_read(self):
         """-> {kernel name: {"launches", "total_ms", "alg_bytes"}} since the last read (synchronises)."""
         arr = (_lib.KernelTime * 64)()

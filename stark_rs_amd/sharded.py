@@ -20,6 +20,13 @@ Layout: the length-L codeword of round r is split in contiguous blocks, rank g h
 When a block would drop below `min_block` elements the codeword is all-gathered once and the
 remaining rounds run replicated on every rank (identical results, no further traffic).
 
+Fri::prove (src/fri.rs:250-311) on top of it (ShardedFriProve): index sampling is replicated
+(every rank hashes the same transcript), each queried element and its authentication path come
+from the rank that owns the leaf -- the path inside the local subtree from the resident nodes,
+the top log2 G siblings from the all-gathered sub-roots -- and rank 0 serializes the proof in the
+reference's object order (src/fri.rs:229-243, src/stream.rs:35-64): byte-identical to the
+single-GPU proof.
+
 Local work goes through a small backend so that the sequencing and the collectives are also
 exercised on CPU tensors with gloo (tests/test_sharded_gloo.py); HipShardBackend is the product.
 """
@@ -38,17 +45,39 @@ class HipShardBackend:
     def tensor(self, values):
         return torch.from_numpy(np.ascontiguousarray(values, dtype=np.uint32).view(np.int32)).to(self.dev)
 
-    def subtree_root(self, cw):
-        """Merkle subtree over a device codeword block -> its 32-byte root (host bytes)."""
-        n = cw.numel()
-        nodes = torch.empty((2 * n - 1) * 32, dtype=torch.uint8, device=self.dev)
-        self.eng.dev_merkle_build(cw.data_ptr(), n, nodes.data_ptr())
-        self.eng.sync()
-        return bytes(nodes[-32:].cpu().numpy())
+    class Tree:
+        """All levels of the Merkle tree over one device codeword block, resident on the device
+        (level 0 first, MerkleTree.nodes of src/merkle.rs:18-33 flattened)."""
 
-    def combine_roots(self, roots):
-        leaves = np.frombuffer(b"".join(roots), dtype=np.uint8).reshape(-1, 32)
-        return self.eng.merkle_commit(leaves) if len(roots) > 1 else roots[0]
+        def __init__(self, be, cw):
+            self.n = cw.numel()
+            self.nodes = torch.empty((2 * self.n - 1) * 32, dtype=torch.uint8, device=be.dev)
+            be.eng.dev_merkle_build(cw.data_ptr(), self.n, self.nodes.data_ptr())
+            be.eng.sync()
+            self.root = bytes(self.nodes[-32:].cpu().numpy())
+
+        def open_many(self, indices):
+            """MerkleTree::open (src/merkle.rs:67-80) for a list of leaves: one device gather."""
+            depth = self.n.bit_length() - 1
+            if not indices or depth == 0:
+                return [[] for _ in indices]
+            rows = [[(2 * self.n - ((2 * self.n) >> l)) + ((i >> l) ^ 1) for l in range(depth)] for i in indices]
+            idx = torch.tensor(rows, dtype=torch.int64, device=self.nodes.device)
+            got = self.nodes.view(-1, 32)[idx.reshape(-1)].cpu().numpy().reshape(len(indices), depth, 32)
+            return [[bytes(got[k, l]) for l in range(depth)] for k in range(len(indices))]
+
+    def subtree(self, cw):
+        return HipShardBackend.Tree(self, cw)
+
+    def values(self, cw, indices):
+        if not indices:
+            return []
+        idx = torch.tensor(indices, dtype=torch.int64, device=cw.device)
+        return [int(v) & 0xFFFFFFFF for v in cw[idx].cpu().tolist()]
+
+    def hash_pairs(self, digests):
+        """[2k x 32] digests -> [k x 32]: Hash::combine of adjacent pairs on the device."""
+        return self.eng.hash_combine_pairs(np.ascontiguousarray(digests, dtype=np.uint8).reshape(-1, 32))
 
     def hash_bytes(self, data):
         return self.eng.hash_bytes(data)
@@ -74,6 +103,34 @@ def num_rounds(domain_length, expansion_factor, num_colinearity_tests):
     return r
 
 
+def top_levels(backend, sub_roots):
+    """Levels of the tree over the G sub-roots (level 0 = the sub-roots), replicated on every rank."""
+    lv = [np.frombuffer(b"".join(sub_roots), dtype=np.uint8).reshape(-1, 32).copy()]
+    while len(lv[-1]) > 1:
+        lv.append(np.asarray(backend.hash_pairs(lv[-1]), dtype=np.uint8).reshape(-1, 32))
+    return lv
+
+
+def sample_index(digest, size):
+    """src/fri.rs:168-174: a u128 accumulator shifted left by 8 per byte keeps, as usize, the last
+    eight digest bytes big-endian."""
+    return int.from_bytes(digest[-8:], "big") % size
+
+
+def sample_indices(hash_bytes, seed, size, reduced_size, number):
+    """src/fri.rs:176-213 (same asserts, same messages)."""
+    assert number <= 2 * reduced_size, "not enough entropy in indices wrt last codeword"
+    assert number <= reduced_size, "cannot sample more indices than available in last codeword"
+    indices, reduced, counter = [], [], 0
+    while len(indices) < number:
+        index = sample_index(hash_bytes(seed + counter.to_bytes(4, "little")), size)
+        counter += 1
+        if index % reduced_size not in reduced:
+            indices.append(index)
+            reduced.append(index % reduced_size)
+    return indices
+
+
 class ShardedFriCommit:
     def __init__(self, backend, p, omega, offset, domain_length, expansion_factor, num_colinearity_tests, rank=0, world=1,
                  group=None, min_block=1 << 12):
@@ -81,7 +138,9 @@ class ShardedFriCommit:
         self.b, self.p, self.rank, self.world, self.group = backend, p, rank, world, group
         self.omega, self.offset, self.N = omega, offset, domain_length
         self.R = num_rounds(domain_length, expansion_factor, num_colinearity_tests)
+        self.t = num_colinearity_tests
         self.min_block = max(min_block, 2)
+        self.rounds = []     # with keep=True: per round {cw, tree, sharded, length, sub_roots}
 
     # -- collectives ---------------------------------------------------------------------------
     def _gather_roots(self, root):
@@ -115,18 +174,23 @@ class ShardedFriCommit:
         return torch.cat(parts)
 
     # -- the round loop ------------------------------------------------------------------------
-    def commit(self, local_block):
+    def commit(self, local_block, keep=False):
         """local_block: this rank's contiguous block of the initial codeword (int32 tensor of u32
-        residues).  Returns (roots [R x bytes], alphas [R-1 unreduced ints], last codeword tensor)."""
+        residues).  Returns (roots [R x bytes], alphas [R-1 unreduced ints], last codeword tensor).
+        keep=True retains every round's local codeword block and tree for the query phase."""
         G, g, p = self.world, self.rank, self.p
         cw, length, sharded = local_block, self.N, G > 1
         omega, offset = self.omega, self.offset
         roots, alphas, transcript = [], [], b""
+        self.rounds = []
         for r in range(self.R):
             if sharded and cw.numel() < self.min_block:
                 cw, sharded = self._all_gather(cw), False
-            sub = self.b.subtree_root(cw)
-            root = self.b.combine_roots(self._gather_roots(sub)) if sharded else sub
+            tree = self.b.subtree(cw)
+            subs = self._gather_roots(tree.root) if sharded else None
+            root = bytes(top_levels(self.b, subs)[-1][0]) if sharded else tree.root
+            if keep:
+                self.rounds.append({"cw": cw, "tree": tree, "sharded": sharded, "length": length, "sub_roots": subs})
             roots.append(root)
             transcript += root                                               # fiat_shamir.absorb, fri.rs:131
             if r == self.R - 1:
@@ -144,3 +208,63 @@ class ShardedFriCommit:
         if sharded:
             cw = self._all_gather(cw)
         return roots, alphas, cw
+
+
+class ShardedFriProve(ShardedFriCommit):
+    """Fri::prove over the sharded commit.  Every rank calls prove(); rank 0 returns
+    (serialized proof bytes, top-level indices), the other ranks (None, top-level indices)."""
+
+    def prove(self, local_block):
+        G, g, R, t = self.world, self.rank, self.R, self.t
+        assert local_block.numel() * G == self.N, "initial codeword length does not match domain length"
+        roots, _alphas, last = self.commit(local_block, keep=True)
+        lens = [self.N >> i for i in range(R)]
+        # replicated: challenge after the last root (src/fri.rs:272), seed = Hash::from_u64(challenge).0
+        challenge = int.from_bytes(self.b.hash_bytes(b"".join(roots))[:8], "little")
+        seed = self.b.hash_bytes(challenge.to_bytes(8, "little"))
+        top = sample_indices(self.b.hash_bytes, seed, lens[1] if R > 1 else lens[0], lens[-1], t)
+
+        # what this rank owns of every (layer, a/b/c, test) opening
+        mine, indices = {}, list(top)
+        for i in range(R - 1):
+            half = lens[i] // 2
+            indices = [x % half for x in indices]                                   # src/fri.rs:283-286
+            for which, rnd, idxs in (("a", i, indices), ("b", i, [x + half for x in indices]), ("c", i + 1, indices)):
+                rd = self.rounds[rnd]
+                if rd["sharded"]:
+                    blk = rd["length"] // G
+                    own = [(s_, j - g * blk) for s_, j in enumerate(idxs) if j // blk == g]
+                    upper = [bytes(lv[(g >> l) ^ 1]) for l, lv in enumerate(top_levels(self.b, rd["sub_roots"])[:-1])]
+                else:                                    # replicated round: rank 0 has everything
+                    own = list(enumerate(idxs)) if g == 0 else []
+                    upper = []
+                loc = [j for _, j in own]
+                vals = self.b.values(rd["cw"], loc)
+                paths = rd["tree"].open_many(loc)
+                for (s_, _), v, pth in zip(own, vals, paths):
+                    mine[(i, which, s_)] = (v, pth + upper)
+        if G > 1:
+            parts = [None] * G if g == 0 else None
+            dist.gather_object(mine, parts, dst=0, group=self.group)
+        else:
+            parts = [mine]
+        if g != 0:
+            return None, top
+
+        got = {}
+        for part in parts:
+            got.update(part)
+        u64 = lambda v: int(v).to_bytes(8, "little")
+        out = bytearray()
+        for r_ in roots:                                                            # src/fri.rs:129
+            out += b"\x00" + r_
+        lastv = [int(v) & 0xFFFFFFFF for v in last.cpu().tolist()]
+        out += b"\x02" + u64(len(lastv)) + b"".join(u64(v) for v in lastv)          # src/fri.rs:151
+        for i in range(R - 1):
+            for s_ in range(t):                                                     # src/fri.rs:229-236
+                out += b"\x02" + u64(3) + b"".join(u64(got[(i, w, s_)][0]) for w in "abc")
+            for s_ in range(t):                                                     # src/fri.rs:239-243
+                for w in "abc":
+                    pth = got[(i, w, s_)][1]
+                    out += b"\x03" + u64(len(pth)) + b"".join(pth)
+        return bytes(out), top

@@ -110,6 +110,24 @@ def test_sharded_commit_backend_world1(eng, oracle):
     assert np.array_equal(last.cpu().numpy().view(np.uint32).astype(np.uint64), wlast)
 
 
+def test_sharded_prove_backend_world1(eng, oracle):
+    """ShardedFriProve with the HIP backend at world size 1: resident trees, one device gather per
+    batch of openings, proof serialized by the host side -- byte for byte the oracle's proof and the
+    C ABI's own smi_fri_prove."""
+    from stark_rs_amd.sharded import HipShardBackend, ShardedFriProve
+    o = oracle
+    n, exp, t, offset = 1 << 14, 8, 8, 3
+    omega = o.ff_prim_nth_root(n)
+    codeword = o.fast_coset_ntt(_vals(o, 6, n // exp), n, omega, offset)
+    be = HipShardBackend(eng)
+    proof, top = ShardedFriProve(be, P, omega, offset, n, exp, t).prove(be.tensor(codeword))
+    cfg = o.fri_cfg(omega, offset, n, exp, t)
+    want, want_top = o.fri_prove(cfg, codeword)
+    assert proof == want and top == want_top
+    got2, top2 = eng.fri_prove(eng.fri_cfg(omega, offset, n, exp, t), codeword)
+    assert bytes(got2) == proof and list(top2) == top
+
+
 def test_cfg3_full_size_lde_and_commit_properties(eng, oracle):
     """BASELINE configs[2]: 2^20-row x 4-column trace, blowup 8 (N = 2^23, the largest domain the
     reference prime has) + Merkle commit.  Size-independent properties: the extension agrees with

@@ -1,4 +1,4 @@
-"""CPU, world_size 2 and 4 over gloo: Fri::commit of one codeword sharded over ranks
+"""CPU, world_size 2 and 4 over gloo: Fri::commit and Fri::prove of one codeword sharded over ranks
 (stark_rs_amd/sharded.py) -- per-rank Merkle subtrees + all-gather of sub-roots, replicated
 Fiat-Shamir, perfect-shuffle fold exchange, final gather -- against the oracle's Fri::commit.
 Local steps run the kernels' own arithmetic through the CPU emulator (hash_core.h, fri_core.h)."""
@@ -28,22 +28,32 @@ class EmuShardBackend:
     def tensor(self, values):
         return torch.from_numpy(np.ascontiguousarray(values, dtype=np.uint32).view(np.int32).copy())
 
-    def _levels(self, digests):
-        while len(digests) > 1:
-            out = np.zeros((len(digests) // 2, 32), dtype=np.uint8)
-            pairs = np.ascontiguousarray(digests.reshape(-1, 64))
-            self.L.emu_node_hash(pairs.ctypes.data_as(C.c_void_p), C.c_size_t(len(out)), out.ctypes.data_as(C.c_void_p))
-            digests = out
-        return bytes(digests[0])
+    class Tree:
+        def __init__(self, be, cw):
+            v = np.ascontiguousarray(cw.numpy().view(np.uint32))
+            d = np.zeros((len(v), 32), dtype=np.uint8)
+            be.L.emu_leaf_hash(v.ctypes.data_as(C.c_void_p), C.c_size_t(len(v)), d.ctypes.data_as(C.c_void_p))
+            self.n, self.levels = len(v), [d]
+            while len(self.levels[-1]) > 1:
+                self.levels.append(be.hash_pairs(self.levels[-1]))
+            self.root = bytes(self.levels[-1][0])
 
-    def subtree_root(self, cw):
-        v = np.ascontiguousarray(cw.numpy().view(np.uint32))
-        d = np.zeros((len(v), 32), dtype=np.uint8)
-        self.L.emu_leaf_hash(v.ctypes.data_as(C.c_void_p), C.c_size_t(len(v)), d.ctypes.data_as(C.c_void_p))
-        return self._levels(d)
+        def open_many(self, indices):
+            return [[bytes(lv[(i >> l) ^ 1]) for l, lv in enumerate(self.levels[:-1])] for i in indices]
 
-    def combine_roots(self, roots):
-        return self._levels(np.frombuffer(b"".join(roots), dtype=np.uint8).reshape(-1, 32).copy())
+    def subtree(self, cw):
+        return EmuShardBackend.Tree(self, cw)
+
+    def values(self, cw, indices):
+        v = cw.numpy().view(np.uint32)
+        return [int(v[i]) for i in indices]
+
+    def hash_pairs(self, digests):
+        digests = np.ascontiguousarray(digests, dtype=np.uint8).reshape(-1, 32)
+        out = np.zeros((len(digests) // 2, 32), dtype=np.uint8)
+        pairs = np.ascontiguousarray(digests.reshape(-1, 64))
+        self.L.emu_node_hash(pairs.ctypes.data_as(C.c_void_p), C.c_size_t(len(out)), out.ctypes.data_as(C.c_void_p))
+        return out
 
     def hash_bytes(self, data):
         out = (C.c_uint8 * 32)()
@@ -85,6 +95,27 @@ def _worker(rank, world, port, logn, expansion, t, offset, min_block, q):
     dist.destroy_process_group()
 
 
+def _prove_worker(rank, world, port, logn, expansion, t, offset, min_block, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from stark_rs_amd.sharded import ShardedFriProve
+    from oracle import oracle as o
+    n = 1 << logn
+    omega = o.ff_prim_nth_root(n)
+    coeffs = o.splitmix64(78, n // expansion) % np.uint64(P)
+    codeword = o.fast_coset_ntt(coeffs, n, omega, offset)
+    be = EmuShardBackend(P, G)
+    blk = n // world
+    fp = ShardedFriProve(be, P, omega, offset, n, expansion, t, rank, world, min_block=min_block)
+    proof, top = fp.prove(be.tensor(codeword[rank * blk:(rank + 1) * blk]))
+    if rank == 0:
+        cfg = o.fri_cfg(omega, offset, n, expansion, t)
+        want, want_top = o.fri_prove(cfg, codeword)
+        q.put(bool(proof == want and top == want_top and o.fri_verify(cfg, proof)))
+    dist.destroy_process_group()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -103,6 +134,26 @@ def test_sharded_fri_commit_gloo(oracle, world, logn, expansion, t, offset, min_
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, logn, expansion, t, offset, min_block, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(240)
+        assert pr.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+@pytest.mark.parametrize("world,logn,expansion,t,offset,min_block", [
+    (2, 10, 4, 4, 3, 64),       # openings come from both ranks' subtrees, later rounds replicated
+    (4, 11, 8, 8, 7, 32),       # two levels above the sub-roots
+    (2, 8, 4, 2, 3, 1 << 12),   # gathered from the start: rank 0 answers every query
+])
+def test_sharded_fri_prove_is_byte_identical_gloo(oracle, world, logn, expansion, t, offset, min_block):
+    """Fri::prove over a sharded codeword: the serialized proof must be byte for byte the oracle's
+    single-process proof, and the oracle's Fri::verify accepts it."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_prove_worker, args=(r, world, port, logn, expansion, t, offset, min_block, q)) for r in range(world)]
     for pr in procs:
         pr.start()
     for pr in procs:
