@@ -127,15 +127,35 @@ extern "C" int emu_ntt(uint64_t p, uint64_t g, const uint32_t *in, uint32_t *out
 
 // ---- hash phases (hash_core.h) --------------------------------------------------------
 #include "hash_core.h"
+// pairs go through the two-hashes-per-state path the Merkle kernels use, the odd tail through the
+// single-hash path
 extern "C" void emu_leaf_hash(const uint32_t *v, size_t n, uint8_t *out) {
-    for (size_t i = 0; i < n; i++) {
+    size_t i = 0;
+    for (; i + 1 < n; i += 2) {
+        uint32_t d0[8], d1[8];
+        hashc::leaf_hash2(v[i], v[i + 1], d0, d1);
+        memcpy(out + 32 * i, d0, 32);
+        memcpy(out + 32 * (i + 1), d1, 32);
+    }
+    for (; i < n; i++) {
         uint32_t d[8];
         hashc::leaf_hash(v[i], d);
         memcpy(out + 32 * i, d, 32);
     }
 }
 extern "C" void emu_node_hash(const uint8_t *pairs, size_t n, uint8_t *out) {
-    for (size_t i = 0; i < n; i++) {
+    size_t i = 0;
+    for (; i + 1 < n; i += 2) {
+        uint32_t l0[8], r0[8], l1[8], r1[8], d0[8], d1[8];
+        memcpy(l0, pairs + 64 * i, 32);
+        memcpy(r0, pairs + 64 * i + 32, 32);
+        memcpy(l1, pairs + 64 * (i + 1), 32);
+        memcpy(r1, pairs + 64 * (i + 1) + 32, 32);
+        hashc::node_hash2(l0, r0, l1, r1, d0, d1);
+        memcpy(out + 32 * i, d0, 32);
+        memcpy(out + 32 * (i + 1), d1, 32);
+    }
+    for (; i < n; i++) {
         uint32_t l[8], r[8], d[8];
         memcpy(l, pairs + 64 * i, 32);
         memcpy(r, pairs + 64 * i + 32, 32);

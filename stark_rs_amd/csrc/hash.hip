@@ -31,36 +31,55 @@ __global__ __launch_bounds__(SMI_HASH_THREADS) void merkle_sub_kernel(const uint
     if (t >= n_threads) return;  // no barriers below: lanes are independent
     const uint32_t per = 1u << K;
     const size_t first = t << K;
-    uint32_t d[8];
-    for (uint32_t i = 0; i < per; i++) {
-        if (FROM_ELEMS) {
-            hashc::leaf_hash(elems[first + i], d);
-            uint4 *dst = nodes + 2 * (first + i);
-            dst[0] = make_uint4(d[0], d[1], d[2], d[3]);
-            dst[1] = make_uint4(d[4], d[5], d[6], d[7]);
-        } else {
+    // Hashes go two at a time (hash_core.h, State2); K >= 1 makes every level but the last even.
+    auto put = [&](uint4 *dst, uint32_t slot, const uint32_t (&d)[8]) {
+        dst[0] = make_uint4(d[0], d[1], d[2], d[3]);
+        dst[1] = make_uint4(d[4], d[5], d[6], d[7]);
+#pragma unroll
+        for (int w = 0; w < 8; w++) stash[(slot * 8 + w) * SMI_HASH_THREADS + tid] = d[w];
+    };
+    auto get = [&](uint32_t slot, uint32_t (&d)[8]) {
+#pragma unroll
+        for (int w = 0; w < 8; w++) d[w] = stash[(slot * 8 + w) * SMI_HASH_THREADS + tid];
+    };
+    if (FROM_ELEMS) {
+        for (uint32_t i = 0; i < per; i += 2) {
+            uint32_t d0[8], d1[8];
+            if (i + 1 < per) {
+                hashc::leaf_hash2(elems[first + i], elems[first + i + 1], d0, d1);
+                put(nodes + 2 * (first + i), i, d0);
+                put(nodes + 2 * (first + i + 1), i + 1, d1);
+            } else {
+                hashc::leaf_hash(elems[first + i], d0);
+                put(nodes + 2 * (first + i), i, d0);
+            }
+        }
+    } else {
+        for (uint32_t i = 0; i < per; i++) {
             const uint4 *src = nodes + 2 * (level_offset(n, lvl_in) + first + i);
             const uint4 a = src[0], b = src[1];
-            d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
-        }
 #pragma unroll
-        for (int w = 0; w < 8; w++) stash[(i * 8 + w) * SMI_HASH_THREADS + tid] = d[w];
+            for (int w = 0; w < 8; w++) stash[(i * 8 + w) * SMI_HASH_THREADS + tid] = w < 4 ? (&a.x)[w] : (&b.x)[w - 4];
+        }
     }
     for (uint32_t j = 1; j <= K; j++) {
         const uint32_t cnt = per >> j;
         uint4 *dst = nodes + 2 * (level_offset(n, lvl_in + j) + (t << (K - j)));
-        for (uint32_t q = 0; q < cnt; q++) {
-            uint32_t l[8], r[8];
-#pragma unroll
-            for (int w = 0; w < 8; w++) {
-                l[w] = stash[((2 * q) * 8 + w) * SMI_HASH_THREADS + tid];
-                r[w] = stash[((2 * q + 1) * 8 + w) * SMI_HASH_THREADS + tid];
+        for (uint32_t q = 0; q < cnt; q += 2) {
+            uint32_t l0[8], r0[8], d0[8];
+            get(2 * q, l0);
+            get(2 * q + 1, r0);
+            if (q + 1 < cnt) {
+                uint32_t l1[8], r1[8], d1[8];
+                get(2 * q + 2, l1);
+                get(2 * q + 3, r1);
+                hashc::node_hash2(l0, r0, l1, r1, d0, d1);
+                put(dst + 2 * q, q, d0);        // slots q, q+1 < 2q: already consumed
+                put(dst + 2 * q + 2, q + 1, d1);
+            } else {
+                hashc::node_hash(l0, r0, d0);
+                put(dst + 2 * q, q, d0);
             }
-            hashc::node_hash(l, r, d);
-            dst[2 * q] = make_uint4(d[0], d[1], d[2], d[3]);
-            dst[2 * q + 1] = make_uint4(d[4], d[5], d[6], d[7]);
-#pragma unroll
-            for (int w = 0; w < 8; w++) stash[(q * 8 + w) * SMI_HASH_THREADS + tid] = d[w];
         }
     }
 }

@@ -299,18 +299,22 @@ SMI_HD void absorb_chunk32(State &st, const uint32_t m[8]) {
 
 // Hash::from_field_elements(&[v as u64]) (src/hash.rs:32-35 as used by src/fri.rs:118-121):
 // 8 message bytes (LE u64 of a u32 residue: the upper four are zero), 1 + 8 mixes.
-SMI_HD void leaf_hash(uint32_t v, uint32_t d[8]) {
+// the 8-byte chunk of a leaf in natural layout: it touches bytes 0..14 -- v_0..v_7 as in
+// absorb32_words (m_4..m_7 = 0), then bytes 8..14 ^= v_1..v_7
+SMI_HD void leaf_absorb_words(uint32_t v, uint32_t P[8]) {
     constexpr InitWords I = make_init_words();
-    uint32_t P[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) P[j] = I.p[j];
-    // the 8-byte chunk touches bytes 0..14: v_0..v_7 as above (m_4..m_7 = 0), bytes 8..14 ^= v_1..v_7
     const uint32_t V0 = rotl3_bytes(add_bytes(P[0], v));
     const uint32_t V1 = rotl3_bytes(P[1] ^ (V0 << 24));
     P[0] = V0;
     P[1] = V1;
     P[2] ^= funnel(V1, V0, 8);
     P[3] ^= V1 >> 8;
+}
+SMI_HD void leaf_hash(uint32_t v, uint32_t d[8]) {
+    uint32_t P[8];
+    leaf_absorb_words(v, P);
     State st;
     from_words(P, st);
     mix_t<false>(st);
@@ -338,6 +342,114 @@ SMI_HD void node_hash(const uint32_t l[8], const uint32_t r[8], uint32_t d[8]) {
     for (int k = 0; k < 8; k++) mix_t<true>(st);
     flush(st);
     to_words(st, d);
+}
+
+// ---- two hashes per state.  Word w holds byte w of hash X in lane 0 and byte w of hash Y in lane 1
+// (32 words for the pair: the same 16 registers per hash).  S-box and linear mix are unchanged
+// per word; the ring add loses both of its lane crossings -- each lane now runs the reference's
+// own recurrence new[i] = s[i] + s[i+1] + new[i-1] from byte 0 to byte 31 -- so the byte-sum tree and
+// the fix-ups of mix_t disappear: 88 instead of 102 VALU instructions per mix and hash.  The Merkle
+// kernels hash leaves and nodes in pairs; single hashes (transcripts, the odd node) use State.
+struct State2 {
+    uint32_t s[32];
+};
+struct Consts2 {
+    uint32_t rc[32], rc502[32];
+};
+constexpr Consts2 make_consts2() {
+    const uint8_t rc[32] = SMI_RC;
+    Consts2 c{};
+    for (int w = 0; w < 32; w++) {
+        c.rc[w] = (uint32_t)rc[w] * 0x00010001u;
+        c.rc502[w] = ((502u * rc[w]) & 0xFFFFu) * 0x00010001u;
+    }
+    return c;
+}
+SMI_HD void flush2(State2 &st) {
+    constexpr Consts2 C = make_consts2();
+#pragma unroll
+    for (int w = 0; w < 32; w++) st.s[w] += C.rc[w];
+}
+template <bool PENDING> SMI_HD void mix2_t(State2 &st) {
+    constexpr Consts2 C = make_consts2();
+    uint32_t *s = st.s;
+    const uint32_t kFE = vreg(0x00FE00FEu), kFF = vreg(0x00FF00FFu), k63 = vreg(0x00630063u);
+    uint32_t r[32];
+#pragma unroll
+    for (int w = 0; w < 32; w++) {
+        const uint32_t t = pk_mad_u16(s[w], 0x01F601F6u, PENDING ? C.rc502[w] : 0u);
+        r[w] = bfi32(kFE, t, t >> 8);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const uint32_t t0 = r[4 * q], t1 = r[4 * q + 1], t2 = r[4 * q + 2], t3 = r[4 * q + 3];
+        const uint32_t T = xor3(xor3(t0, t1, t2), t3, k63);
+        s[4 * q] = (T ^ t2) & kFF;
+        s[4 * q + 1] = (T ^ t1) & kFF;
+        s[4 * q + 2] = (T ^ t3) & kFF;
+        s[4 * q + 3] = (T ^ t0) & kFF;
+    }
+    // src/hash.rs:77-81 as written, both lanes at once; a lane never exceeds 32*2*255 + 1020 < 2^16
+    uint32_t N[32];
+    N[0] = add3(s[0], s[1], s[31]);
+#pragma unroll
+    for (int w = 1; w < 31; w++) N[w] = add3(N[w - 1], s[w], s[w + 1]);
+    N[31] = add3(s[31], N[0], N[30]);
+#pragma unroll
+    for (int w = 0; w < 32; w++) s[w] = N[w];
+}
+SMI_HD void mix2(State2 &st) {
+    mix2_t<false>(st);
+    flush2(st);
+}
+SMI_HD void from_words2(const uint32_t X[8], const uint32_t Y[8], State2 &st) {
+#pragma unroll
+    for (int w = 0; w < 32; w++) {
+        const uint32_t k = (uint32_t)w & 3u;
+        st.s[w] = perm8(Y[w >> 2], X[w >> 2], 0x0C000C00u | ((4u + k) << 16) | k);
+    }
+}
+SMI_HD void to_words2(const State2 &st, uint32_t X[8], uint32_t Y[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t *q = st.s + 4 * j;
+        X[j] = perm8(q[1], q[0], 0x0C0C0400u) | perm8(q[3], q[2], 0x04000C0Cu);
+        Y[j] = perm8(q[1], q[0], 0x0C0C0602u) | perm8(q[3], q[2], 0x06020C0Cu);
+    }
+}
+// two leaves / two nodes at once: the same digests as leaf_hash / node_hash on each
+SMI_HD void leaf_hash2(uint32_t v0, uint32_t v1, uint32_t d0[8], uint32_t d1[8]) {
+    uint32_t X[8], Y[8];
+    leaf_absorb_words(v0, X);
+    leaf_absorb_words(v1, Y);
+    State2 st;
+    from_words2(X, Y, st);
+    mix2_t<false>(st);
+#pragma unroll 1
+    for (int k = 0; k < 8; k++) mix2_t<true>(st);
+    flush2(st);
+    to_words2(st, d0, d1);
+}
+SMI_HD void node_hash2(const uint32_t l0[8], const uint32_t r0[8], const uint32_t l1[8], const uint32_t r1[8], uint32_t d0[8],
+                       uint32_t d1[8]) {
+    constexpr InitWords I = make_init_words();
+    uint32_t X[8], Y[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) X[j] = Y[j] = I.p[j];
+    absorb32_words(X, l0);
+    absorb32_words(Y, l1);
+    State2 st;
+    from_words2(X, Y, st);
+    mix2(st);
+    to_words2(st, X, Y);
+    absorb32_words(X, r0);
+    absorb32_words(Y, r1);
+    from_words2(X, Y, st);
+    mix2_t<false>(st);
+#pragma unroll 1
+    for (int k = 0; k < 8; k++) mix2_t<true>(st);
+    flush2(st);
+    to_words2(st, d0, d1);
 }
 
 // Hash::from_bytes for an arbitrary message (src/hash.rs:7-30); single lane, used by the

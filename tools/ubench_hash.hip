@@ -17,6 +17,18 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, int mixes) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+__global__ __launch_bounds__(256) void k2(uint32_t *out, int mixes) {
+    extern __shared__ uint32_t lds[];
+    hashc::State2 st;
+    for (int w = 0; w < 32; w++) st.s[w] = (threadIdx.x * 2654435761u + w * 40503u + blockIdx.x) & 0x00FF00FFu;
+#pragma unroll 1
+    for (int i = 0; i < mixes; i++) hashc::mix2_t<true>(st);
+    uint32_t s = 0;
+    for (int w = 0; w < 32; w++) s ^= st.s[w];
+    if (s == 0x12345678u) lds[threadIdx.x] = s;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 int main() {
     uint32_t *d;
     const int blocks = 256 * 40, mixes = 512;
@@ -38,6 +50,21 @@ int main() {
         int occ = 0;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, 256, l * 1024);
         printf("lds %3d KB  blocks/CU %d  %8.3f ms  %6.2f G mix/s  (%.1f ns per mix per CU-wave-slot)\n", l, occ, ms, n_mix / ms / 1e6, 0.0);
+    }
+    for (int l : lds_kb) {   // two hashes per state: count both
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        k2<<<blocks / 2, 256, l * 1024>>>(d, mixes);
+        (void)hipDeviceSynchronize();
+        (void)hipEventRecord(e0);
+        k2<<<blocks / 2, 256, l * 1024>>>(d, mixes);
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        int occ = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k2, 256, l * 1024);
+        printf("pairs: lds %3d KB  blocks/CU %d  %8.3f ms  %6.2f G mix/s\n", l, occ, ms, (double)blocks * 256 * mixes / ms / 1e6);
     }
     return 0;
 }
