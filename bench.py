@@ -90,10 +90,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    # Rehearsal knobs (one-GPU box): SMI_BENCH_BACKEND=gloo and SMI_BENCH_DEVICE=0 run N ranks on one
+    # card to exercise the distributed control flow; the driver's runs use neither.
+    backend = os.environ.get("SMI_BENCH_BACKEND", "nccl")
+    if "SMI_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["SMI_BENCH_DEVICE"])
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
@@ -298,7 +306,8 @@ def main():
             if rank == 0:
                 result["sharded_fri_prove_bytes"] = len(proof)
           except Exception as e:
-            result["sharded_fri_commit_error"] = str(e)
+            import traceback
+            result["sharded_fri_error"] = f"{type(e).__name__}: {e} | {traceback.format_exc(limit=3)}"
 
         if rank == 0 and world == 1:
             result["cpu_baseline"] = cpu_baseline()

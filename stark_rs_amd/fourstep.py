@@ -26,6 +26,9 @@ class HipBackend:
 
     def __init__(self, engine):
         self.eng = engine
+        # share torch's stream: buffers pass between torch ops / RCCL and the engine's kernels
+        with torch.cuda.device(f"cuda:{engine.device}"):
+            engine.set_stream(torch.cuda.current_stream().cuda_stream)
 
     def empty(self, n):
         return torch.empty(n, dtype=torch.int32, device=f"cuda:{self.eng.device}")
@@ -41,7 +44,7 @@ class HipBackend:
         self.eng.dev_transpose(src.data_ptr(), dst.data_ptr(), rows, cols)
 
     def fence(self):
-        # the engine enqueues on its own stream; RCCL runs on torch's: order them
+        # RCCL may run on its own internal stream: drain ours before handing buffers over
         self.eng.sync()
 
 

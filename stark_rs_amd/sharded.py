@@ -41,6 +41,11 @@ class HipShardBackend:
     def __init__(self, engine):
         self.eng = engine
         self.dev = f"cuda:{engine.device}"
+        # One stream for everything: the codeword blocks are produced and consumed by torch ops
+        # (cat, indexing, the collectives) and by the engine's kernels in turn; on two streams every
+        # hand-over would need its own fence (a missed one after torch.cat let ranks diverge).
+        with torch.cuda.device(self.dev):
+            engine.set_stream(torch.cuda.current_stream().cuda_stream)
 
     def tensor(self, values):
         return torch.from_numpy(np.ascontiguousarray(values, dtype=np.uint32).view(np.int32)).to(self.dev)
