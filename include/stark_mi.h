@@ -50,6 +50,7 @@ enum {
     SMI_ERR_LEN_MISMATCH = -14,       /* assert!(domain.len() == values.len()) src/univariate/interpolate.rs:10 */
     SMI_ERR_EMPTY_DOMAIN = -15,       /* assert!(domain.len() > 0)            src/univariate/interpolate.rs:11 */
     SMI_ERR_WRONG_FIELD = -16,        /* assert!(self.p == 998244353)         src/ff.rs:192,216 */
+    SMI_ERR_POLY_DIV_BY_ZERO = -18,   /* "No division by zero"                src/univariate/div.rs:7-9 */
     SMI_ERR_NO_ROUNDS = -17,          /* num_rounds()==0: proof the reference's verify rejects */
     /* contract violations that have no reference counterpart */
     SMI_ERR_BAD_ARG = -50,
@@ -121,6 +122,14 @@ int smi_poly_scale(smi_ctx *ctx, const uint64_t *coeffs, size_t n, uint64_t fact
 /* Polynomial::mul (src/univariate/mul.rs:6-29) by NTT: out gets na+nb-1 coefficients (*n_out),
  * or *n_out = 0 when either operand is the zero polynomial, as the reference returns `vec![]`. */
 int smi_poly_mul(smi_ctx *ctx, const uint64_t *a, size_t na, const uint64_t *b, size_t nb, uint64_t *out, size_t *n_out);
+/* Polynomial::div (src/univariate/div.rs:6-42): quotient and remainder of a / b, via the power-series
+ * inverse of the reversed divisor (NTT products) instead of the reference's O(n*m) subtraction loop.
+ * q gets deg a - deg b + 1 coefficients (*nq), r gets deg b coefficients (*nr; the reference's
+ * remainder vector may carry further trailing zeros -- Polynomial equality ignores them).  When
+ * deg a < deg b: *nq = 0 and r = a unchanged (na coefficients), as div.rs:10-18.  A zero divisor
+ * gives SMI_ERR_POLY_DIV_BY_ZERO.  q needs room for na, r for max(na, nb) coefficients. */
+int smi_poly_div(smi_ctx *ctx, const uint64_t *a, size_t na, const uint64_t *b, size_t nb, uint64_t *q, size_t *nq, uint64_t *r,
+                 size_t *nr);
 /* Checks in O(n) whether domain[k] == domain[0]*omega_n^k (the fast-path contract of
  * interpolate_domain / eval_domain); returns SMI_OK and *offset = domain[0], or
  * SMI_ERR_NOT_GEOMETRIC. */

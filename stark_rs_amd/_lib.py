@@ -99,6 +99,7 @@ def lib():
         "smi_coset_ntt": (i32, [vp, vp, sz, vp, C.c_uint32, C.c_uint64]),
         "smi_poly_scale": (i32, [vp, vp, sz, C.c_uint64, vp]),
         "smi_poly_mul": (i32, [vp, vp, sz, vp, sz, vp, C.POINTER(sz)]),
+        "smi_poly_div": (i32, [vp, vp, sz, vp, sz, vp, C.POINTER(sz), vp, C.POINTER(sz)]),
         "smi_domain_is_geometric": (i32, [vp, vp, sz, u64p]),
         "smi_lde": (i32, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, vp]),
         "smi_trace_pack": (i32, [vp, vp, sz, sz, vp]),

@@ -15,6 +15,7 @@ const char *smi_status_string(int status) {
     case SMI_OK: return "ok";
     case SMI_ERR_NO_INVERSE: return "no inverse";
     case SMI_ERR_DIV_BY_ZERO: return "no division by zero";
+    case SMI_ERR_POLY_DIV_BY_ZERO: return "No division by zero";
     case SMI_ERR_NOT_POW2: return "n must be a power of two";
     case SMI_ERR_ROOT_TOO_LARGE: return "n > 2^23 not supported by this modulus";
     case SMI_ERR_EMPTY_LEAVES: return "Cannot create tree from empty leaves";
@@ -472,6 +473,118 @@ int smi_poly_mul(smi_ctx *ctx, const uint64_t *a, size_t na, const uint64_t *b, 
     HIP_TRY(ctx, hipMemcpyAsync(out, stage, n * 8, hipMemcpyDeviceToHost, ctx->stream));
     *n_out = n;
     return check_flag(ctx);
+}
+
+// Polynomial::div (src/univariate/div.rs:6-42).  The reference subtracts one shifted multiple of the
+// divisor per quotient coefficient (O(n*m) u128 divisions); here the quotient comes from the
+// power-series inverse of the reversed divisor (Newton iteration, every product an NTT product on
+// the device) and the remainder from one more product:
+//     rev(q) = rev(a) * rev(b)^-1  mod x^k,   k = deg a - deg b + 1,      r = a - q*b  (deg r < deg b).
+// Quotient and remainder of a division are unique, so the coefficients are the reference's.
+__global__ void reverse_kernel(const uint32_t *src, size_t deg, uint32_t *dst, size_t k) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < k; i += step) dst[i] = i <= deg ? src[deg - i] : 0u;   // dst[i] = coefficient deg-i, zero beyond
+}
+__global__ void two_minus_kernel(uint32_t *e, size_t n, uint32_t p) {   // e <- 2 - e as a power series
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += step) e[i] = fp_sub(i == 0 ? 2u % p : 0u, e[i], p);
+}
+__global__ void sub_kernel(const uint32_t *a, const uint32_t *b, uint32_t *out, size_t n, uint32_t p) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += step) out[i] = fp_sub(a[i], b[i], p);
+}
+static uint32_t ew_grid(size_t n) { size_t g = (n + 255) / 256; return (uint32_t)(g > 2048 ? 2048 : (g ? g : 1)); }
+// first `keep` coefficients of x*y into out (f1, f2: scratch of `cap` elements, cap a power of two >= nx+ny-1)
+static int dev_mul_trunc(smi_ctx *ctx, const uint32_t *x, size_t nx, const uint32_t *y, size_t ny, uint32_t *out, size_t keep,
+                         uint32_t *f1, uint32_t *f2) {
+    const size_t n = nx + ny - 1;
+    uint32_t L = 0;
+    while (((size_t)1 << L) < n) L++;
+    const size_t N = (size_t)1 << L;
+    SMI_TRY(dev_ntt(ctx, x, f1, L, nx, 1, nx, N, 0, 1, 1));
+    SMI_TRY(dev_ntt(ctx, y, f2, L, ny, 1, ny, N, 0, 1, 1));
+    pointwise_mul_kernel<<<ew_grid(N), 256, 0, ctx->stream>>>(f1, f2, N, ctx->fs.F);
+    HIP_TRY(ctx, hipGetLastError());
+    SMI_TRY(dev_ntt(ctx, f1, f1, L, N, 1, N, N, 1, 1, 1));
+    HIP_TRY(ctx, hipMemcpyAsync(out, f1, (keep < n ? keep : n) * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    if (keep > n) HIP_TRY(ctx, hipMemsetAsync(out + n, 0, (keep - n) * 4, ctx->stream));
+    return SMI_OK;
+}
+int smi_poly_div(smi_ctx *ctx, const uint64_t *a, size_t na, const uint64_t *b, size_t nb, uint64_t *q, size_t *nq, uint64_t *r,
+                 size_t *nr) {
+    if (!ctx || !nq || !nr || (na && !a) || (nb && !b)) return SMI_ERR_BAD_ARG;
+    const uint32_t p = ctx->fs.F.p;
+    ptrdiff_t da = -1, db = -1;   // Polynomial::deg (src/univariate/mod.rs:37-46)
+    for (size_t i = 0; i < na; i++) { if (a[i] >= p) return smi_fail(ctx, SMI_ERR_NON_CANONICAL, "coefficient >= p"); if (a[i]) da = (ptrdiff_t)i; }
+    for (size_t i = 0; i < nb; i++) { if (b[i] >= p) return smi_fail(ctx, SMI_ERR_NON_CANONICAL, "coefficient >= p"); if (b[i]) db = (ptrdiff_t)i; }
+    if (db < 0) return smi_fail(ctx, SMI_ERR_POLY_DIV_BY_ZERO, "No division by zero");
+    if (da < db) {   // quotient vec![], remainder numer.clone() (div.rs:10-18)
+        *nq = 0;
+        *nr = na;
+        if (na && !r) return SMI_ERR_BAD_ARG;
+        if (na) memcpy(r, a, na * 8);
+        return SMI_OK;
+    }
+    if (!q || (db && !r)) return SMI_ERR_BAD_ARG;
+    const size_t k = (size_t)(da - db) + 1, n = (size_t)da + 1, m = (size_t)db + 1;
+    size_t cap = 1;
+    while (cap < 2 * n) cap <<= 1;   // every product below has fewer than 2n terms
+    uint32_t capL = 0;
+    while (((size_t)1 << capL) < cap) capL++;
+    if (capL > ctx->fs.K) return smi_fail(ctx, SMI_ERR_ROOT_TOO_LARGE, "dividend too long for this modulus");
+    uint32_t *buf = nullptr;
+    uint64_t *stage = nullptr;
+    if (hipMalloc((void **)&buf, (n + 2 * m + 4 * k + 2 * cap) * 4) != hipSuccess || hipMalloc((void **)&stage, n * 8) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(buf);
+        return smi_fail(ctx, SMI_ERR_OOM, "poly_div scratch");
+    }
+    uint32_t *A = buf, *B = A + n, *rA = B + m, *rB = rA + k, *g = rB + k, *e = g + k, *R = e + k, *f1 = R + m, *f2 = f1 + cap;
+    int rc = SMI_OK;
+    auto run = [&]() -> int {
+        HIP_TRY(ctx, hipMemcpyAsync(stage, a, n * 8, hipMemcpyHostToDevice, ctx->stream));
+        SMI_TRY(launch_narrow(ctx, stage, A, n, 0));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // stage is reused for b
+        HIP_TRY(ctx, hipMemcpyAsync(stage, b, m * 8, hipMemcpyHostToDevice, ctx->stream));
+        SMI_TRY(launch_narrow(ctx, stage, B, m, 0));
+        reverse_kernel<<<ew_grid(k), 256, 0, ctx->stream>>>(A, (size_t)da, rA, k);
+        reverse_kernel<<<ew_grid(k), 256, 0, ctx->stream>>>(B, (size_t)db, rB, k);
+        // g = rB^-1 mod x^k: g_1 = 1 / lead(b), g_2t = g_t * (2 - rB * g_t) mod x^2t
+        const uint32_t g0 = h_inv(ctx, (uint32_t)b[db]);
+        HIP_TRY(ctx, hipMemsetAsync(g, 0, k * 4, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(g, &g0, 4, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // g0 lives on this frame
+        for (size_t t = 1; t < k; t <<= 1) {
+            const size_t t2 = 2 * t < k ? 2 * t : k;
+            SMI_TRY(dev_mul_trunc(ctx, rB, t2, g, t, e, t2, f1, f2));
+            two_minus_kernel<<<ew_grid(t2), 256, 0, ctx->stream>>>(e, t2, p);
+            SMI_TRY(dev_mul_trunc(ctx, g, t, e, t2, g, t2, f1, f2));
+        }
+        SMI_TRY(dev_mul_trunc(ctx, rA, k, g, k, e, k, f1, f2));            // rev(q)
+        reverse_kernel<<<ew_grid(k), 256, 0, ctx->stream>>>(e, k - 1, rA, k);   // q, in rA
+        SMI_TRY(launch_widen(ctx, rA, stage, k));
+        HIP_TRY(ctx, hipMemcpyAsync(q, stage, k * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (db) {   // r = a - q*b: the terms of degree >= deg b cancel, db coefficients remain
+            SMI_TRY(dev_mul_trunc(ctx, rA, k, B, m, R, (size_t)db, f1, f2));
+            sub_kernel<<<ew_grid((size_t)db), 256, 0, ctx->stream>>>(A, R, R, (size_t)db, p);
+            SMI_TRY(launch_widen(ctx, R, stage, (size_t)db));
+            HIP_TRY(ctx, hipMemcpyAsync(r, stage, (size_t)db * 8, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        return check_flag(ctx);
+    };
+    rc = run();
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(buf);
+    (void)hipFree(stage);
+    if (rc != SMI_OK) return rc;
+    *nq = k;
+    *nr = (size_t)db;
+    return SMI_OK;
 }
 
 int smi_lde(smi_ctx *ctx, const uint64_t *cols, uint32_t n_cols, uint32_t log_n, uint32_t log_blowup, uint64_t trace_offset,

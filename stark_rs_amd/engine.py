@@ -125,6 +125,16 @@ class Engine:
         self._ck(self.L.smi_poly_mul(self.h, a.ctypes.data, len(a), b.ctypes.data, len(b), out.ctypes.data, C.byref(n)))
         return out[:n.value].copy()
 
+    def poly_div(self, a, b):
+        """Polynomial::div (div.rs:6-42) -> (quotient, remainder) by NTT products (power-series inverse)."""
+        a, b = _u64(a), _u64(b)
+        q = np.empty(max(len(a), 1), dtype=np.uint64)
+        r = np.empty(max(len(a), len(b), 1), dtype=np.uint64)
+        nq, nr = C.c_size_t(), C.c_size_t()
+        self._ck(self.L.smi_poly_div(self.h, a.ctypes.data, len(a), b.ctypes.data, len(b), q.ctypes.data, C.byref(nq),
+                                     r.ctypes.data, C.byref(nr)))
+        return q[:nq.value].copy(), r[:nr.value].copy()
+
     def domain_is_geometric(self, domain):
         d = _u64(domain)
         off = C.c_uint64()

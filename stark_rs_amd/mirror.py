@@ -201,6 +201,39 @@ class Polynomial:
     mul = staticmethod(lambda lhs, rhs: lhs * rhs)
 
     @staticmethod
+    def div(numer, denom):
+        """Polynomial::div (div.rs:6-42) -> (quotient, remainder), NTT products on the device."""
+        q, r = numer.field.engine().poly_div(_vals(numer.coeffs), _vals(denom.coeffs))
+        f = numer.field
+        return Polynomial([FieldElement(int(v), f) for v in q], f), Polynomial([FieldElement(int(v), f) for v in r], f)
+
+    def __truediv__(self, o):
+        return Polynomial.div(self, o)
+
+    @staticmethod
+    def intdiv(numer, denom):                                       # div.rs:44-48
+        q, r = Polynomial.div(numer, denom)
+        assert r.is_zero()
+        return q
+
+    @staticmethod
+    def modulo(numer, denom):                                       # div.rs:50-53
+        return Polynomial.div(numer, denom)[1]
+
+    @staticmethod
+    def zerofier(domain):
+        """mod.rs:77-96: prod (x - d).  The reference multiplies the factors in one by one; here a
+        balanced product tree of device NTT products gives the same polynomial."""
+        field = domain[0].field
+        polys = [Polynomial([FieldElement((-d.value) % field.p, field), field.one()], field) for d in domain]
+        while len(polys) > 1:
+            nxt = [polys[i] * polys[i + 1] for i in range(0, len(polys) - 1, 2)]
+            if len(polys) % 2:
+                nxt.append(polys[-1])
+            polys = nxt
+        return polys[0]
+
+    @staticmethod
     def interpolate_domain(domain, values):
         """interpolate.rs:6-44 for a geometric domain offset*omega_n^k (the fast-path contract)."""
         if len(domain) != len(values):

@@ -123,6 +123,43 @@ def test_scale(m, field):
 
 
 # ---- src/hash.rs tests
+def test_div_and_zerofier(m, field, oracle):
+    """src/univariate/div.rs:83-262 and mod.rs:320-413 on the mirror (device NTT products)."""
+    f, Poly = field, m.Polynomial
+    q, r = Poly(fe(f, 2, 3, 1), f) / Poly(fe(f, 1, 1), f)               # test_division_basic
+    assert q.deg() == 1 and [c.value for c in q.coeffs] == [2, 1] and r.is_zero()
+    q, r = Poly.div(Poly(fe(f, 1, 0, 1), f), Poly(fe(f, 1, 1), f))       # test_division_with_remainder
+    assert q.deg() == 1 and r.deg() == 0 and r.coeffs[0].value == 2
+    dividend = Poly(fe(f, 1, 1), f)                                      # test_division_lower_degree_dividend
+    q, r = Poly.div(dividend, Poly(fe(f, 1, 0, 1), f))
+    assert q.is_zero() and r == dividend
+    with pytest.raises(m.PANIC, match="No division by zero"):            # test_division_by_zero
+        Poly.div(dividend, Poly([], f))
+    dividend = Poly(fe(f, 6, 11, 6, 1), f)                               # test_division_verification
+    divisor = Poly(fe(f, 2, 1), f)
+    q, r = Poly.div(dividend, divisor)
+    back = q * divisor
+    back = Poly([f.add(c, r.coeffs[i]) if i < len(r.coeffs) else c for i, c in enumerate(back.coeffs)], f)
+    assert back == dividend
+    assert Poly.intdiv(dividend, divisor) == q and Poly.modulo(dividend, divisor).is_zero()
+    z = Poly.zerofier(fe(f, 5))                                          # test_zerofier_single_point
+    assert z.deg() == 1 and [c.value for c in z.coeffs] == [P - 5, 1] and z.eval(f.new_element(5)).value == 0
+    z = Poly.zerofier(fe(f, 2, 3))                                       # test_zerofier_two_points
+    assert [c.value for c in z.coeffs] == [6, P - 5, 1]
+    z = Poly.zerofier(fe(f, 1, 2, 3))                                    # test_zerofier_three_points
+    assert [c.value for c in z.coeffs] == [P - 6, 11, P - 6, 1]
+    assert [c.value for c in Poly.zerofier(fe(f, 0)).coeffs] == [0, 1]   # test_zerofier_zero_point
+    assert Poly.zerofier(fe(f, 1, 2)).eval(f.new_element(5)).value == 12  # test_zerofier_nonzero_evaluation
+    for n in (1, 2, 5, 10, 33):                                          # test_zerofier_degree (+ oracle values)
+        dom = list(range(1, n + 1))
+        z = Poly.zerofier(fe(f, *dom))
+        assert z.deg() == n and [c.value for c in z.coeffs] == oracle.poly_zerofier(dom)
+    # a zerofier divides what vanishes on its domain
+    zs = Poly.zerofier(fe(f, 3, 9, 27, 81))
+    g = Poly(fe(f, 7, 0, 5, 1, 2), f)
+    assert Poly.modulo(g * zs, zs).is_zero() and Poly.intdiv(g * zs, zs) == g
+
+
 def test_hash(m):
     H = m.Hash
     assert H.from_bytes(b"hello") == H.from_bytes(b"hello")          # test_hash_deterministic

@@ -148,6 +148,53 @@ def test_poly_mul_equals_schoolbook_oracle(eng, oracle):
         assert list(eng.poly_mul(a, b)) == o.poly_mul(a, b)
 
 
+def _trim(c):
+    c = [int(v) for v in c]
+    while c and c[-1] == 0:
+        c.pop()
+    return c
+
+
+def test_poly_div_reference_cases_and_oracle(eng, oracle):
+    """Polynomial::div (div.rs:6-42) by power-series inversion on the device.  The reference's own
+    tests (div.rs:83-262) with their values, then random sizes against the oracle's restatement of
+    the subtraction loop; quotient exact, remainder compared as polynomials (trailing zeros are not
+    significant: mod.rs:57-68) and the identity a = q*b + r checked with the device product."""
+    import stark_rs_amd as s
+    o = oracle
+    q, r = eng.poly_div([2, 3, 1], [1, 1])                       # test_division_basic
+    assert list(q) == [2, 1] and _trim(r) == []
+    q, r = eng.poly_div([1, 0, 1], [1, 1])                       # test_division_with_remainder
+    assert len(_trim(q)) == 2 and _trim(r) == [2]
+    q, r = eng.poly_div([2, 4, 6], [2])                          # test_division_by_constant
+    assert list(q) == [1, 2, 3] and _trim(r) == []
+    q, r = eng.poly_div([1, 1], [1, 0, 1])                       # test_division_lower_degree_dividend
+    assert len(q) == 0 and list(r) == [1, 1]
+    with pytest.raises(s.StarkMiError, match="No division by zero"):   # test_division_by_zero
+        eng.poly_div([1, 2], [])
+    with pytest.raises(s.StarkMiError, match="No division by zero"):
+        eng.poly_div([1, 2], [0, 0])
+    q, r = eng.poly_div([], [1, 1])                              # test_division_zero_dividend
+    assert len(q) == 0 and _trim(r) == []
+    q, r = eng.poly_div([3, 2, 1], [3, 2, 1])                    # test_division_same_polynomials
+    assert list(q) == [1] and _trim(r) == []
+    q, r = eng.poly_div([7, 14], [7])                            # test_division_with_field_arithmetic
+    assert list(q) == [1, 2] and _trim(r) == []
+    q, r = eng.poly_div([5, 0, 0, 0, 1, 0, 0], [0, 1, 0])        # leading zeros on both sides
+    assert (list(q), _trim(r)) == (o.poly_div([5, 0, 0, 0, 1], [0, 1])[0], _trim(o.poly_div([5, 0, 0, 0, 1], [0, 1])[1]))
+    for na, nb in ((9, 5), (157, 100), (700, 325), (1024, 1), (1024, 1024), (1500, 2), (4097, 2049)):
+        a, b = _vals(o, 3 * na, na), _vals(o, 5 * nb, nb)
+        q, r = eng.poly_div(a, b)
+        wq, wr = o.poly_div(a, b) if na * nb <= 300000 else (None, None)
+        if wq is not None:
+            assert list(q) == wq and _trim(r) == _trim(wr), (na, nb)
+        # a = q*b + r
+        qb = [int(v) for v in eng.poly_mul(q, b)] if len(q) else []
+        back = [(x + (int(r[i]) if i < len(r) else 0)) % P for i, x in enumerate(qb + [0] * (na - len(qb)))]
+        assert _trim(back) == _trim(a), (na, nb)
+        assert len(_trim(r)) < len(_trim(b))
+
+
 def test_lde_cfg3_small(eng, oracle):
     """4 columns, blowup 8: interpolate on the subgroup, evaluate on the coset g*<W>."""
     o = oracle
