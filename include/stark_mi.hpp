@@ -11,6 +11,8 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <utility>
+#include <algorithm>
 #include <vector>
 
 #include "stark_mi.h"
@@ -185,6 +187,23 @@ struct Polynomial {
         std::vector<uint64_t> c = values_of(coeffs), out(c.size());
         if (!c.empty()) check(smi_poly_scale(field.ctx(), c.data(), c.size(), factor.value % field.p, out.data()), field.ctx());
         return Polynomial(elements_of(out, field), field);
+    }
+    static Polynomial mul(const Polynomial &l, const Polynomial &r) {  // mul.rs:6-29, NTT product on the device
+        std::vector<uint64_t> a = values_of(l.coeffs), b = values_of(r.coeffs), out(a.size() + b.size() + 1);
+        size_t n = 0;
+        check(smi_poly_mul(l.field.ctx(), a.data(), a.size(), b.data(), b.size(), out.data(), &n), l.field.ctx());
+        out.resize(n);
+        return Polynomial(elements_of(out, l.field), l.field);
+    }
+    // div.rs:6-42 -> (quotient, remainder); panics "No division by zero"
+    static std::pair<Polynomial, Polynomial> div(const Polynomial &numer, const Polynomial &denom) {
+        std::vector<uint64_t> a = values_of(numer.coeffs), b = values_of(denom.coeffs);
+        std::vector<uint64_t> q(a.size() + 1), r(std::max(a.size(), b.size()) + 1);
+        size_t nq = 0, nr = 0;
+        check(smi_poly_div(numer.field.ctx(), a.data(), a.size(), b.data(), b.size(), q.data(), &nq, r.data(), &nr), numer.field.ctx());
+        q.resize(nq);
+        r.resize(nr);
+        return {Polynomial(elements_of(q, numer.field), numer.field), Polynomial(elements_of(r, numer.field), numer.field)};
     }
 };
 

@@ -55,6 +55,20 @@ int main() {
     const uint64_t P = 998244353;
     FiniteField field(P);
 
+    // src/univariate/div.rs:83-123, :169-178 and mul.rs on the device
+    {
+        auto P3 = [&](std::vector<uint64_t> v) { return Polynomial(elements_of(v, field), field); };
+        auto qr = Polynomial::div(P3({2, 3, 1}), P3({1, 1}));                       // test_division_basic
+        EXPECT(qr.first.deg() == 1 && qr.first.coeffs[0].value == 2 && qr.first.coeffs[1].value == 1 && qr.second.is_zero());
+        qr = Polynomial::div(P3({1, 0, 1}), P3({1, 1}));                            // test_division_with_remainder
+        EXPECT(qr.first.deg() == 1 && qr.second.deg() == 0 && qr.second.coeffs[0].value == 2);
+        EXPECT(panics_with([&] { Polynomial::div(P3({1, 2}), P3({})); }, "No division by zero"));
+        Polynomial prod = Polynomial::mul(P3({1, 0, 2}), P3({3, 0, 4}));            // test_mul_sparse
+        EXPECT(prod == P3({3, 0, 10, 0, 8}));
+        qr = Polynomial::div(prod, P3({3, 0, 4}));
+        EXPECT(qr.first == P3({1, 0, 2}) && qr.second.is_zero());
+    }
+
     // src/ff.rs panics
     EXPECT(panics_with([&] { field.inv(field.zero()); }, "no inverse"));
     EXPECT(panics_with([&] { field.prim_nth_root(6); }, "n must be a power of two"));
