@@ -90,6 +90,15 @@ def main():
     fri[str(nn)] = {"expansion": e, "t": t, "offset": off, "coeff_seed": 99, "proof_sha256": hashlib.sha256(proof).hexdigest(),
                     "proof_len": len(proof), "top_indices": top}
     g["fri"] = fri
+    # ---- Polynomial::div (div.rs): small verbatim, a 700 / 325 case by SHA-256 (quotient ‖ trimmed remainder)
+    a9, b5 = vals(27, 9), vals(25, 5)
+    q, r = o.poly_div(a9, b5)
+    g["poly_div_9_by_5"] = {"a": [int(x) for x in a9], "b": [int(x) for x in b5], "q": q, "r": r}
+    a, b = vals(3 * 700, 700), vals(5 * 325, 325)
+    q, r = o.poly_div(a, b)
+    while r and r[-1] == 0:
+        r.pop()
+    g["poly_div_700_by_325"] = {"seed_a": 2100, "seed_b": 1625, "q_sha256": sha(q), "r_sha256": sha(r), "len_q": len(q), "len_r": len(r)}
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden.json")
     json.dump(g, open(out, "w"), indent=1)
     print("wrote", out, os.path.getsize(out), "bytes")

@@ -63,6 +63,32 @@ def eng():
     e.close()
 
 
+def _trimmed(c):
+    c = [int(v) for v in c]
+    while c and c[-1] == 0:
+        c.pop()
+    return c
+
+
+def test_oracle_reproduces_poly_div_fixtures(oracle):
+    o = oracle
+    kat = GOLD["poly_div_9_by_5"]
+    assert o.poly_div(kat["a"], kat["b"]) == (kat["q"], kat["r"])
+    big = GOLD["poly_div_700_by_325"]
+    q, r = o.poly_div(o.splitmix64(big["seed_a"], 700) % np.uint64(P), o.splitmix64(big["seed_b"], 325) % np.uint64(P))
+    assert (sha(q), sha(_trimmed(r)), len(q)) == (big["q_sha256"], big["r_sha256"], big["len_q"])
+
+
+@pytest.mark.gpu
+def test_gpu_poly_div_fixtures(eng, oracle):
+    kat = GOLD["poly_div_9_by_5"]
+    q, r = eng.poly_div(kat["a"], kat["b"])
+    assert [int(v) for v in q] == kat["q"] and _trimmed(r) == _trimmed(kat["r"])
+    big = GOLD["poly_div_700_by_325"]
+    q, r = eng.poly_div(oracle.splitmix64(big["seed_a"], 700) % np.uint64(P), oracle.splitmix64(big["seed_b"], 325) % np.uint64(P))
+    assert (sha(q), sha(_trimmed(r)), len(q), len(_trimmed(r))) == (big["q_sha256"], big["r_sha256"], big["len_q"], big["len_r"])
+
+
 @pytest.mark.gpu
 def test_gpu_small_fixtures(eng):
     for m, d in GOLD["hash_bytes"].items():
