@@ -2,14 +2,16 @@
 //
 // Replaces Hash::from_field_elements / Hash::combine (reference src/hash.rs:32-46) as they
 // are used per codeword element and per tree node by Fri::commit (src/fri.rs:118-127) and
-// MerkleTree::new (src/merkle.rs:11-38).  One hash per lane, state in VGPRs in the
-// paired-lane layout of hash_core.h.  The tree is kept whole on the device (`nodes` of
-// src/merkle.rs:6, levels back to back) so `open` is a gather and nothing is rebuilt.
+// MerkleTree::new (src/merkle.rs:11-38).  Hashes run in VGPRs, two per lane at a time (State2 of
+// hash_core.h; a single one where a level is odd).  The tree is kept whole on the device
+// (`nodes` of src/merkle.rs:6, levels back to back) so `open` is a gather and nothing is rebuilt.
 //
 // merkle_sub_kernel: every lane owns 2^K adjacent inputs and builds their K-level subtree
 // on its own (2^K leaf hashes + 2^K - 1 node hashes at full lane occupancy, no cross-lane
 // traffic); child digests wait in an LDS stash laid out [slot][word][thread] (bank =
-// thread, conflict free).  Roofline: integer VALU (~1.6k ops per hash), not HBM.
+// thread, conflict free).  merkle_top_kernel: one workgroup finishes a tree from its last
+// <= 2048 digests.  Roofline: integer VALU issue (~0.9k instructions per leaf hash, ~1.2k per node
+// hash), not HBM -- DESIGN.md section 3.
 #include "hash_core.h"
 #include "internal.h"
 

@@ -1,9 +1,10 @@
 // hash_core.h -- the reference's 32-byte hash (src/hash.rs:7-99) for one lane (host+device).
 //
 // State layout ("paired lanes"): 16 u32 words, word w holds state byte w in bits 0..7 and
-// state byte w+16 in bits 16..23; bits 8..15 / 24..31 are headroom.  With it
-//   * the byte S-box  rotl1(b*251)^0x63  is one 24-bit multiply by 502 on two bytes at once
-//     (bit 8 of 502*b is the rotated-out bit), src/hash.rs:88-94;
+// state byte w+16 in bits 16..23; bits 8..15 / 24..31 are headroom.  (State2, further down, puts
+// byte w of two different hashes in the two lanes instead: what the Merkle kernels use.)  With it
+//   * the byte S-box  rotl1(b*251)^0x63  is one packed 16-bit multiply-add by 502 on two bytes at
+//     once (bit 8 of 502*b is the rotated-out bit), src/hash.rs:88-94;
 //   * the 4-byte linear mix (src/hash.rs:64-75) is plain XORs of whole words: groups g and
 //     g+4 share words 4g..4g+3;
 //   * the sequential in-place ring add (src/hash.rs:77-81) runs on both lanes at once, one
