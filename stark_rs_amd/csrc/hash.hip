@@ -86,28 +86,30 @@ __global__ __launch_bounds__(SMI_HASH_THREADS) void merkle_sub_kernel(const uint
     }
 }
 
-// The top of a tree: one workgroup takes a level of at most SMI_TOP_MAX digests (or that many
-// codeword elements) and builds every level above it, a barrier per level, the current level
-// held in LDS as [word][slot].  These levels are pure latency (one node hash deep each, a few
-// wavefronts wide): as separate launches they cost ~6.5 us per level, here one hash latency.
+// Upper levels: one workgroup takes a chunk of at most SMI_TOP_MAX adjacent digests of one level (or
+// that many codeword elements) and builds every level above them down to the chunk's single root,
+// a barrier per level, the current level held in LDS as [word][slot].  grid.x = chunk, grid.y =
+// tree.  These levels are pure latency (one node hash deep each): as two-level launches of
+// merkle_sub_kernel they cost ~6.5 us per level, here one hash latency (~3.8 us).
 #define SMI_TOP_MAX 2048
 #define SMI_TOP_THREADS (SMI_TOP_MAX / 2)
 template <bool FROM_ELEMS>
 __global__ __launch_bounds__(SMI_TOP_THREADS) void merkle_top_kernel(const uint32_t *__restrict__ elems, uint4 *nodes, size_t n,
-                                                                      uint32_t lvl_in, uint32_t count_in, size_t elem_stride,
+                                                                      uint32_t lvl_in, uint32_t chunk, size_t elem_stride,
                                                                       size_t node_stride) {
     __shared__ uint32_t buf[8 * SMI_TOP_MAX];
-    elems += (size_t)blockIdx.x * elem_stride;
-    nodes += (size_t)blockIdx.x * node_stride;
+    elems += (size_t)blockIdx.y * elem_stride;
+    nodes += (size_t)blockIdx.y * node_stride;
     const uint32_t tid = threadIdx.x;
+    const size_t first = (size_t)blockIdx.x * chunk;   // position of the chunk inside level lvl_in
     uint32_t d[8];
-    for (uint32_t i = tid; i < count_in; i += SMI_TOP_THREADS) {
+    for (uint32_t i = tid; i < chunk; i += SMI_TOP_THREADS) {
         if (FROM_ELEMS) {
-            hashc::leaf_hash(elems[i], d);
-            nodes[2 * (size_t)i] = make_uint4(d[0], d[1], d[2], d[3]);
-            nodes[2 * (size_t)i + 1] = make_uint4(d[4], d[5], d[6], d[7]);
+            hashc::leaf_hash(elems[first + i], d);
+            nodes[2 * (first + i)] = make_uint4(d[0], d[1], d[2], d[3]);
+            nodes[2 * (first + i) + 1] = make_uint4(d[4], d[5], d[6], d[7]);
         } else {
-            const uint4 *src = nodes + 2 * (level_offset(n, lvl_in) + i);
+            const uint4 *src = nodes + 2 * (level_offset(n, lvl_in) + first + i);
             const uint4 a = src[0], b = src[1];
             d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
         }
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(SMI_TOP_THREADS) void merkle_top_kernel(const uint3
     }
     __syncthreads();
     uint32_t lvl = lvl_in;
-    for (uint32_t cnt = count_in; cnt > 1; cnt >>= 1) {   // cnt, lvl are workgroup-uniform
+    for (uint32_t cnt = chunk; cnt > 1; cnt >>= 1) {   // cnt, lvl are workgroup-uniform
         const uint32_t half = cnt >> 1;
         lvl++;
         if (tid < half) {
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(SMI_TOP_THREADS) void merkle_top_kernel(const uint3
                 r[w] = buf[w * SMI_TOP_MAX + 2 * tid + 1];
             }
             hashc::node_hash(l, r, d);
-            uint4 *dst = nodes + 2 * (level_offset(n, lvl) + tid);
+            uint4 *dst = nodes + 2 * (level_offset(n, lvl) + (first >> (lvl - lvl_in)) + tid);
             dst[0] = make_uint4(d[0], d[1], d[2], d[3]);
             dst[1] = make_uint4(d[4], d[5], d[6], d[7]);
         }
@@ -254,20 +256,35 @@ int launch_merkle_batch(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t
         const int k = e ? atoi(e) : 2;
         return (uint32_t)(k < 1 ? 1 : (k > 3 ? 3 : k));
     }();
+    // chunk workgroups per launch below which the chunk kernel takes over (one per CU; tuning knob)
+    const size_t TOP_BLOCKS = [] {
+        const char *e = getenv("SMI_MERKLE_TOP_BLOCKS");
+        return (size_t)(e ? atoi(e) : 256);
+    }();
     if (from_elems && depth == 0) {
         for (uint32_t y = 0; y < n_trees; y++) SMI_TRY(launch_leaf_hash(ctx, d_elems + y * elem_stride, 1, d_nodes + y * node_stride_bytes));
         return SMI_OK;
     }
     while (lvl < depth || from_elems) {
-        if (count <= SMI_TOP_MAX) {   // the rest of the tree in one launch per tree
-            const double hashed = from_elems ? 2.0 * (double)count - 1.0 : (double)count - 1.0;
+        // Once what is left fits the chip as one wave of chunk workgroups, the per-level latency of
+        // the chunk kernel beats two-level launches: up to SMI_TOP_MAX digests (11 levels) per launch.
+        const size_t chunk = count < SMI_TOP_MAX ? count : SMI_TOP_MAX;
+        const size_t n_chunks = count / chunk;
+        if (n_chunks * n_trees <= TOP_BLOCKS) {
+            const double hashed = (from_elems ? 2.0 * (double)count : (double)count) - (double)n_chunks;
             ProfScope ps(ctx, "merkle_top_kernel", ((from_elems ? 4.0 : 32.0) * (double)count + 32.0 * hashed) * n_trees);
+            const dim3 grid((uint32_t)n_chunks, n_trees);
             if (from_elems)
-                merkle_top_kernel<true><<<n_trees, SMI_TOP_THREADS, 0, ctx->stream>>>(d_elems, nodes, n, 0, (uint32_t)count, elem_stride, node_stride);
+                merkle_top_kernel<true><<<grid, SMI_TOP_THREADS, 0, ctx->stream>>>(d_elems, nodes, n, 0, (uint32_t)chunk, elem_stride, node_stride);
             else
-                merkle_top_kernel<false><<<n_trees, SMI_TOP_THREADS, 0, ctx->stream>>>(nullptr, nodes, n, lvl, (uint32_t)count, 0, node_stride);
+                merkle_top_kernel<false><<<grid, SMI_TOP_THREADS, 0, ctx->stream>>>(nullptr, nodes, n, lvl, (uint32_t)chunk, 0, node_stride);
             HIP_TRY(ctx, hipGetLastError());
-            return SMI_OK;
+            from_elems = false;
+            uint32_t up = 0;
+            while (((size_t)1 << up) < chunk) up++;
+            lvl += up;
+            count = n_chunks;
+            continue;
         }
         uint32_t K = depth - lvl < KMAX ? depth - lvl : KMAX;
         const size_t threads = count >> K;
