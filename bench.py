@@ -64,7 +64,20 @@ def cpu_baseline():
     c20 = o.fast_intt(big, w20, 1)
     o.fast_coset_ntt(c20, 1 << 23, w23, 3)
     t4 = time.perf_counter()
+    # the commit side of the path on the CPU: MerkleTree::new over 2^18 digests and one fold of a
+    # 2^18-element codeword (the reference's per-element exp + two xgcd inversions)
+    m = 1 << 18
+    digests = np.frombuffer(splitmix64(5, 4 * m).tobytes(), dtype=np.uint8).reshape(m, 32)
+    t5 = time.perf_counter()
+    o.merkle_new(digests)
+    t6 = time.perf_counter()
+    cw = splitmix64(6, m) % np.uint64(p)
+    wm = o.ff_prim_nth_root(m)
+    o.fri_fold_codeword(o.fri_cfg(wm, 3, m, 8, 32), cw, 0x0123456789ABCDEF, 3, wm)
+    t7 = time.perf_counter()
     return {
+        "merkle_node_hashes_per_s": (m - 1) / (t6 - t5), "fold_elements_per_s": (m // 2) / (t7 - t6),
+        "commit_sample": f"oracle MerkleTree::new over 2^18 digests ({t6 - t5:.2f}s), Fri::fold_codeword of 2^18 elements ({t7 - t6:.2f}s), 1 thread",
         "value": (n + N) / (t2 - t0), "unit": "field-elements/s", "cores": 1, "kind": "port",
         "sample": f"oracle interpolate_domain n=2^10 ({t1 - t0:.2f}s) + eval_domain d=2^10,N=2^13 ({t2 - t1:.2f}s), "
                   "single thread, same u128 %% p arithmetic and O(n^3)/O(N*d) algorithms as the reference",
