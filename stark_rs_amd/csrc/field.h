@@ -44,6 +44,17 @@ SMI_HD uint32_t umulhi32(uint32_t a, uint32_t b) {
 }
 SMI_HD uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
+// A value held in a VGPR.  On gfx950 the simple VALU ops (add, sub, and, or, xor, right shifts,
+// v_bitop3) issue in 2 cycles per wave only while every source is a VGPR or an inline constant;
+// with an SGPR or literal source they take 4, like the multiplies and the other three-operand
+// ops (measured, tools/ubench_valu.hip).  The empty asm is pure: it can be hoisted out of loops.
+SMI_HD uint32_t vreg(uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SMI_NO_VREG)   // SMI_NO_VREG: tuning builds only
+    asm("" : "+v"(c));
+#endif
+    return c;
+}
+
 // a*b*R^-1 mod p for a*b < p*2^32 (e.g. a < p, b arbitrary u32).  Result in [0,p).
 // t = a*b, m = lo(t)*p^-1 mod 2^32; t - m*p is a multiple of 2^32 and (t - m*p)/2^32 =
 // hi(t) - hi(m*p) lies in (-p, p) -- the low words cancel exactly.  v_mul_lo/hi_u32 issue at the

@@ -63,17 +63,6 @@ SMI_HD uint32_t pk_mad_u16(uint32_t a, uint32_t m, uint32_t c) {
 #endif
 }
 
-// A constant held in a VGPR.  On gfx950 the simple VALU ops (add, sub, and, or, xor, right shifts,
-// v_bitop3) issue in 2 cycles per wave only while every source is a VGPR or an inline constant; with
-// an SGPR or literal source they take 4 like the multiplies and the other three-operand ops
-// (measured, tools/ubench_valu.hip).  The empty asm is pure, so it is hoisted out of the mix loops.
-SMI_HD uint32_t vreg(uint32_t c) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(SMI_NO_VREG)   // SMI_NO_VREG: tuning builds only
-    asm("" : "+v"(c));
-#endif
-    return c;
-}
-
 // (mask & a) | (~mask & b) and a ^ b ^ c as single VALU ops (the compiler otherwise splits them).
 SMI_HD uint32_t bfi32(uint32_t mask, uint32_t a, uint32_t b) {
 #if defined(__HIP_DEVICE_COMPILE__)
