@@ -95,6 +95,31 @@ def test_transpose_and_fourstep_world1(eng2, oracle):
         assert np.array_equal(got, want)
 
 
+def test_copy_probe_twins_run_and_leave_the_engine_intact(eng, oracle):
+    """smi_ctx_copy_probe (bench.py's pattern-copy roofline leg): every pass launches its copy-only
+    twin under a name of its own; switching it off restores the transform."""
+    o = oracle
+    logn, lb, W = 16, 3, 2
+    n, N = 1 << logn, 1 << (logn + lb)
+    cols = np.stack([_vals(o, 40 + c, n) for c in range(W)])
+    d_in = _upload(eng, cols)
+    d_out = eng.dev_alloc(W * N * 4)
+    eng.copy_probe(True)
+    eng.profile(True)
+    eng.dev_lde(d_in, W, logn, lb, d_out, 1, G)
+    names = eng.profile_read()
+    eng.profile(False)
+    eng.copy_probe(False)
+    assert names and all(k.startswith("ntt_copy_probe<") for k in names), names
+    eng.dev_lde(d_in, W, logn, lb, d_out, 1, G)
+    got = eng.dev_download(d_out, W * N).reshape(W, N)
+    w, Wn = o.ff_prim_nth_root(n), o.ff_prim_nth_root(N)
+    for c in range(W):
+        assert np.array_equal(got[c], o.fast_coset_ntt(o.fast_intt(cols[c], w, 1), N, Wn, G))
+    eng.dev_free(d_in)
+    eng.dev_free(d_out)
+
+
 def test_sharded_commit_backend_world1(eng, oracle):
     """stark_rs_amd/sharded.py with the HIP backend at world size 1 (the collectives are covered by
     the gloo test): subtree kernel, device transcript hash and the shard fold entry point."""
