@@ -342,7 +342,7 @@ struct ProofStream {
     }
 };
 
-// src/fri.rs:8-311 (prover side)
+// src/fri.rs:8-504
 class Fri {
   public:
     FieldElement offset, omega;
@@ -380,6 +380,116 @@ class Fri {
             proof_stream.push(o);
         }
         return std::vector<size_t>(top.begin(), top.begin() + num_colinearity_tests);
+    }
+
+    // Fri::sample_indices (src/fri.rs:176-213); digests from the device hash
+    std::vector<size_t> sample_indices(const Hash &seed, size_t size, size_t reduced_size, size_t number) const {
+        if (number > 2 * reduced_size) throw Panic(SMI_ERR_SAMPLE_ENTROPY, "not enough entropy in indices wrt last codeword");
+        if (number > reduced_size) throw Panic(SMI_ERR_SAMPLE_TOO_MANY, "cannot sample more indices than available in last codeword");
+        std::vector<size_t> indices, reduced;
+        for (uint32_t counter = 0; indices.size() < number; counter++) {
+            uint8_t msg[36];
+            std::memcpy(msg, seed.b, 32);
+            for (int k = 0; k < 4; k++) msg[32 + k] = (uint8_t)(counter >> (8 * k));
+            const Hash h = Hash::from_bytes(msg, 36);
+            uint64_t acc = 0;   // sample_index (:168-174): the last eight digest bytes, big-endian
+            for (int k = 24; k < 32; k++) acc = (acc << 8) | h.b[k];
+            const size_t index = (size_t)(acc % size), r = index % reduced_size;
+            if (std::find(reduced.begin(), reduced.end(), r) == reduced.end()) {
+                indices.push_back(index);
+                reduced.push_back(r);
+            }
+        }
+        return indices;
+    }
+    // Fri::verify (src/fri.rs:313-504): the reference's control flow on the host; leaf hashes and
+    // Merkle paths checked in batches on the device (smi_hash_leaves, smi_merkle_verify_batch) and
+    // the last-layer low-degree test as an inverse NTT instead of the reference's O(L^3) Lagrange
+    // interpolation.  false where the reference prints and returns false.
+    bool verify(ProofStream &proof_stream, FiatShamir &fiat_shamir, std::vector<std::pair<size_t, FieldElement>> &polynomial_values) const {
+        smi_ctx *ctx = field.ctx();
+        const uint64_t p = field.p, t = num_colinearity_tests, R = num_rounds();
+        auto mulm = [&](uint64_t a, uint64_t b) { return (uint64_t)((unsigned __int128)a * b % p); };
+        auto powm = [&](uint64_t b, uint64_t e) { uint64_t r = 1 % p; b %= p; while (e) { if (e & 1) r = mulm(r, b); b = mulm(b, b); e >>= 1; } return r; };
+        std::vector<Hash> roots;
+        std::vector<uint64_t> alphas;
+        for (uint64_t i = 0; i < R; i++) {   // :325-334
+            const ProofObject *o = proof_stream.pop();
+            if (!o || o->tag != ProofObject::MerkleRoot) return false;
+            roots.push_back(o->hash);
+            fiat_shamir.absorb(o->hash.b, 32);
+            alphas.push_back(fiat_shamir.challenge(field).value);
+        }
+        const ProofObject *lo = proof_stream.pop();   // :337-342
+        if (!lo || lo->tag != ProofObject::FieldElements || roots.empty()) return false;
+        const std::vector<uint64_t> last = lo->elements;
+        const size_t n_last = last.size();
+        if (n_last == 0 || (n_last & (n_last - 1))) throw Panic(SMI_ERR_LEAVES_NOT_POW2, "Number of leaves must be power of 2");
+        std::vector<uint8_t> digests(32 * n_last);
+        Hash last_root;
+        check(smi_hash_leaves(ctx, last.data(), n_last, digests.data()), ctx);   // :349-357
+        check(smi_merkle_commit(ctx, digests.data(), n_last, last_root.b), ctx);
+        if (last_root != roots.back()) return false;
+        const size_t degree_bound = n_last / expansion_factor;   // :360-365
+        if (degree_bound == 0) return false;
+        uint64_t last_omega = omega.value, last_offset = offset.value;
+        for (uint64_t i = 0; i + 1 < R; i++) { last_omega = mulm(last_omega, last_omega); last_offset = mulm(last_offset, last_offset); }
+        uint64_t want_root = 0;
+        check(smi_prim_nth_root(ctx, n_last, &want_root), ctx);
+        if (last_omega != want_root) return false;   // the domain of the last layer must be offset * <omega_L>
+        std::vector<uint64_t> coeffs(n_last), re_eval(n_last);
+        if (n_last > 1) {
+            check(smi_intt(ctx, last.data(), coeffs.data(), log2_exact(n_last), last_offset), ctx);
+            check(smi_coset_ntt(ctx, coeffs.data(), n_last, re_eval.data(), log2_exact(n_last), last_offset), ctx);
+            if (re_eval != last) return false;       // :384-390
+        } else {
+            coeffs = last;
+        }
+        for (size_t i = degree_bound; i < n_last; i++)
+            if (coeffs[i] != 0) return false;        // :392-397: degree <= degree_bound - 1
+        const Hash seed = Hash::from_u64(fiat_shamir.challenge(field).value);   // :400-405
+        const std::vector<size_t> top = sample_indices(seed, domain_length >> 1, domain_length >> (R - 1), t);
+        uint64_t om = omega.value, off = offset.value;
+        for (uint64_t r = 0; r + 1 < R; r++) {       // :408-502
+            const size_t half = domain_length >> (r + 1);
+            std::vector<uint64_t> c_idx(t), b_idx(t), aa(t), bb(t), cc(t);
+            for (uint64_t s = 0; s < t; s++) {
+                c_idx[s] = top[s] % half;
+                b_idx[s] = c_idx[s] + half;
+                const ProofObject *o = proof_stream.pop();
+                if (!o || o->tag != ProofObject::FieldElements || o->elements.size() != 3) return false;
+                aa[s] = o->elements[0]; bb[s] = o->elements[1]; cc[s] = o->elements[2];
+                if (r == 0) {
+                    polynomial_values.emplace_back((size_t)c_idx[s], field.new_element(aa[s]));
+                    polynomial_values.emplace_back((size_t)b_idx[s], field.new_element(bb[s]));
+                }
+                const uint64_t ax = mulm(off, powm(om, c_idx[s])), bx = mulm(off, powm(om, b_idx[s])), cx = alphas[r] % p;
+                // test_colinearity (:507-525): (y1-y0)(x2-x0) == (y2-y0)(x1-x0)
+                const uint64_t l = mulm((p + bb[s] - aa[s]) % p, (p + cx - ax) % p), rr = mulm((p + cc[s] - aa[s]) % p, (p + bx - ax) % p);
+                if (l != rr) return false;
+            }
+            std::vector<std::vector<uint8_t>> paths(3);   // a, b, c paths, each t x depth x 32
+            size_t depth[3] = {0, 0, 0};
+            for (uint64_t s = 0; s < t; s++)
+                for (int w = 0; w < 3; w++) {
+                    const ProofObject *o = proof_stream.pop();
+                    if (!o || o->tag != ProofObject::MerklePath) return false;
+                    if (s == 0) depth[w] = o->path.size();
+                    if (o->path.size() != depth[w]) return false;
+                    for (const Hash &h : o->path) paths[w].insert(paths[w].end(), h.b, h.b + 32);
+                }
+            const std::vector<uint64_t> *vals[3] = {&aa, &bb, &cc}, *idxs[3] = {&c_idx, &b_idx, &c_idx};
+            const Hash *rt[3] = {&roots[r], &roots[r], &roots[r + 1]};
+            for (int w = 0; w < 3; w++) {
+                std::vector<uint8_t> leaf(32 * t), ok(t);
+                check(smi_hash_leaves(ctx, vals[w]->data(), t, leaf.data()), ctx);
+                check(smi_merkle_verify_batch(ctx, leaf.data(), idxs[w]->data(), paths[w].data(), t, depth[w], rt[w]->b, ok.data()), ctx);
+                for (uint8_t f : ok) if (!f) return false;
+            }
+            om = mulm(om, om);
+            off = mulm(off, off);
+        }
+        return true;
     }
 
   private:

@@ -43,6 +43,21 @@ static void fri_case(size_t n, size_t expansion, size_t t, uint64_t offset_v, st
     EXPECT(verifier_stream.serialize() == proof_bytes);
     EXPECT(prover_fiat_shamir.transcript.size() == 32 * fri.num_rounds());
 
+    // the mirror's own Fri::verify (device hashes / paths / iNTT) accepts, and rejects a tampered proof
+    {
+        FiatShamir vfs;
+        std::vector<std::pair<size_t, FieldElement>> pv;
+        EXPECT(fri.verify(verifier_stream, vfs, pv));
+        EXPECT(pv.size() == 2 * t);
+        for (const auto &iv : pv) EXPECT(iv.second == codeword[iv.first]);   // the opened top-layer values (fri.rs:437-442)
+        std::vector<uint8_t> bad = proof_bytes;
+        bad[bad.size() / 2] ^= 1;
+        ProofStream tampered = ProofStream::deserialize(bad);
+        FiatShamir vfs2;
+        std::vector<std::pair<size_t, FieldElement>> pv2;
+        EXPECT(!fri.verify(tampered, vfs2, pv2));
+    }
+
     so_fri_cfg cfg{field.p, omega.value, offset.value, n, expansion, t};
     int ok = so_fri_verify(&cfg, proof_bytes.data(), proof_bytes.size(), nullptr, nullptr, nullptr);
     if (ok != 1) std::printf("verify rejected: %s %s\n", so_fri_last_reject(), so_last_panic());
