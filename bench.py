@@ -13,7 +13,8 @@ all ranks per second.  Reported beside it in the same JSON line:
                    the same launch as a pure copy with the pass's access pattern (pattern_copy);
   * cpu_baseline-- the op-for-op CPU oracle of the reference path on a bounded sample (rank 0);
   * prove_ms    -- end-to-end build-defined prove (LDE + 4 column commits + combine + Fri::prove)
-                   of the same trace, with per-stage HIP-event times;
+                   of the same trace, with per-stage HIP-event times; prove_row_leaves_ms: the same
+                   with one row-leaf tree instead of the four column trees (a build-defined variant);
   * ntt_2p20    -- BASELINE configs[1]: 2^20-point forward+inverse on the reference prime;
   * four_step   -- (N > 1) one 2^26-point NTT sharded over the N GPUs with the RCCL all-to-all.
 """
@@ -236,6 +237,17 @@ def main():
             result["prove_proof_bytes"] = len(res["proof"])
         except Exception as e:  # reported, never hidden
             result["prove_error"] = str(e)
+        # build-defined variant: one tree over the rows of the extended trace instead
+        # of one per column -- four columns are one 32-byte chunk, so the commit costs a quarter
+        try:
+            eng.dev_stark_prove(trace.data_ptr(), N_COLS, LOG_ROWS, LOG_BLOWUP, N_TESTS, row_leaves=True)
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            res = eng.dev_stark_prove(trace.data_ptr(), N_COLS, LOG_ROWS, LOG_BLOWUP, N_TESTS, timed=True, row_leaves=True)
+            result["prove_row_leaves_ms"] = 1e3 * (time.perf_counter() - tp)
+            result["prove_row_leaves_stage_ms"] = res["stage_ms"]
+        except Exception as e:
+            result["prove_row_leaves_error"] = str(e)
 
         # ---- BASELINE configs[1]: 2^20-point forward + inverse on the reference prime
         if rank == 0:

@@ -227,6 +227,11 @@ int smi_dev_lde(smi_ctx *ctx, const uint32_t *d_cols, uint32_t n_cols, uint32_t 
  * level 0 (leaf digests) first, root last -- `nodes` of src/merkle.rs:18-33 back to back. */
 int smi_dev_hash_leaves(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_digests);
 int smi_dev_merkle_build(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_nodes);
+/* Row-leaf tree (build-defined leaf rule): leaf i = Hash::from_field_elements of row i
+ * of n_cols columns (column c at d_cols + c*col_stride), i.e. src/hash.rs:32-35 applied to the row
+ * instead of to a single element; with 4 columns a leaf is one 32-byte chunk and costs what a
+ * single-element leaf costs, so one tree replaces four. */
+int smi_dev_merkle_build_rows(smi_ctx *ctx, const uint32_t *d_cols, uint32_t n_cols, size_t col_stride, size_t n, uint8_t *d_nodes);
 /* Tree over precomputed 32-byte leaves already at d_nodes[0 .. n*32). */
 int smi_dev_merkle_from_digests(smi_ctx *ctx, size_t n, uint8_t *d_nodes);
 /* Fri::fold_codeword with alpha read from device memory (*d_alpha: one unreduced u64). */
@@ -256,7 +261,9 @@ int smi_dev_combine_columns(smi_ctx *ctx, const uint32_t *d_cols, uint32_t n_col
  * serialized FRI ProofStream (smi_free); stage_ms (optional) gets the HIP-event times of
  * {lde, column commits, combine, fri} in milliseconds. */
 typedef struct {
-    uint32_t log_n, log_blowup, n_cols, reserved;
+    uint32_t log_n, log_blowup, n_cols;
+    uint32_t row_leaves;   /* 0: one tree per column, one element per leaf (the reference's leaf rule, src/fri.rs:118-121);
+                              1: one tree over the rows (smi_dev_merkle_build_rows) -- a build-defined variant */
     uint64_t trace_offset, lde_offset, num_colinearity_tests;
 } smi_stark_cfg;
 int smi_dev_stark_prove(smi_ctx *ctx, const smi_stark_cfg *cfg, const uint32_t *d_trace_cols, uint8_t *column_roots,

@@ -33,7 +33,7 @@ class KernelTime(C.Structure):
 
 
 class StarkCfg(C.Structure):
-    _fields_ = [("log_n", C.c_uint32), ("log_blowup", C.c_uint32), ("n_cols", C.c_uint32), ("reserved", C.c_uint32),
+    _fields_ = [("log_n", C.c_uint32), ("log_blowup", C.c_uint32), ("n_cols", C.c_uint32), ("row_leaves", C.c_uint32),
                 ("trace_offset", C.c_uint64), ("lde_offset", C.c_uint64), ("num_colinearity_tests", C.c_uint64)]
 
 
@@ -133,6 +133,7 @@ def lib():
         "smi_dev_lde": (i32, [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, vp]),
         "smi_dev_hash_leaves": (i32, [vp, vp, sz, vp]),
         "smi_dev_merkle_build": (i32, [vp, vp, sz, vp]),
+        "smi_dev_merkle_build_rows": (i32, [vp, vp, C.c_uint32, sz, sz, vp]),
         "smi_dev_merkle_from_digests": (i32, [vp, sz, vp]),
         "smi_dev_fri_fold": (i32, [vp, vp, sz, vp, C.c_uint64, C.c_uint64, vp]),
         "smi_dev_fri_fold_shard": (i32, [vp, vp, vp, sz, sz, sz, vp, C.c_uint64, C.c_uint64, vp]),

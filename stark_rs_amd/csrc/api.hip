@@ -627,6 +627,13 @@ int smi_dev_merkle_build(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_
     if (!is_pow2(n)) return smi_fail(ctx, SMI_ERR_LEAVES_NOT_POW2, nullptr);
     return launch_merkle(ctx, d_elems, n, d_nodes);
 }
+int launch_merkle_rows(smi_ctx *ctx, const uint32_t *d_cols, uint32_t n_cols, size_t col_stride, size_t n, uint8_t *d_nodes);
+int smi_dev_merkle_build_rows(smi_ctx *ctx, const uint32_t *d_cols, uint32_t n_cols, size_t col_stride, size_t n, uint8_t *d_nodes) {
+    if (!ctx || !d_cols || !d_nodes) return SMI_ERR_BAD_ARG;
+    if (n == 0) return smi_fail(ctx, SMI_ERR_EMPTY_LEAVES, nullptr);
+    if (!is_pow2(n)) return smi_fail(ctx, SMI_ERR_LEAVES_NOT_POW2, nullptr);
+    return launch_merkle_rows(ctx, d_cols, n_cols, col_stride, n, d_nodes);
+}
 int smi_dev_merkle_from_digests(smi_ctx *ctx, size_t n, uint8_t *d_nodes) {
     if (!ctx || !d_nodes) return SMI_ERR_BAD_ARG;
     if (n == 0) return smi_fail(ctx, SMI_ERR_EMPTY_LEAVES, nullptr);

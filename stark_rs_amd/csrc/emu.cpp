@@ -163,6 +163,22 @@ extern "C" void emu_node_hash(const uint8_t *pairs, size_t n, uint8_t *out) {
         memcpy(out + 32 * i, d, 32);
     }
 }
+// rows of W residues, row-major in `v`: pairs through row_hash2 when W <= 4, the rest through row_hash
+extern "C" void emu_row_hash(const uint32_t *v, size_t n_rows, int W, uint8_t *out) {
+    size_t i = 0;
+    if (W >= 1 && W <= 4)
+        for (; i + 1 < n_rows; i += 2) {
+            uint32_t d0[8], d1[8];
+            hashc::row_hash2(v + i * W, v + (i + 1) * W, W, d0, d1);
+            memcpy(out + 32 * i, d0, 32);
+            memcpy(out + 32 * (i + 1), d1, 32);
+        }
+    for (; i < n_rows; i++) {
+        uint32_t d[8];
+        hashc::row_hash(v + i * W, W, d);
+        memcpy(out + 32 * i, d, 32);
+    }
+}
 extern "C" void emu_hash_bytes(const uint8_t *msg, size_t len, uint8_t *out) {
     uint32_t d[8];
     hashc::hash_bytes(msg, len, d);

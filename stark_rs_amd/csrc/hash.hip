@@ -16,13 +16,15 @@
 #include "internal.h"
 
 #define SMI_HASH_THREADS 256
+#define SMI_ROW_MAX 64   // columns per row leaf
 
 __device__ __forceinline__ size_t level_offset(size_t n, uint32_t lvl) { return 2 * n - ((2 * n) >> lvl); }
 
 template <bool FROM_ELEMS>
 __global__ __launch_bounds__(SMI_HASH_THREADS) void merkle_sub_kernel(const uint32_t *__restrict__ elems, uint4 *nodes,
                                                                         size_t n, uint32_t lvl_in, size_t count_in,
-                                                                        uint32_t K, size_t elem_stride, size_t node_stride) {
+                                                                        uint32_t K, size_t elem_stride, size_t node_stride,
+                                                                        uint32_t row_cols, size_t row_stride) {
     extern __shared__ __attribute__((aligned(16))) uint32_t stash[];  // [1<<K][8][SMI_HASH_THREADS]
     // blockIdx.y = tree of a batch of equally sized trees (e.g. the columns of a trace)
     elems += (size_t)blockIdx.y * elem_stride;
@@ -44,7 +46,29 @@ __global__ __launch_bounds__(SMI_HASH_THREADS) void merkle_sub_kernel(const uint
 #pragma unroll
         for (int w = 0; w < 8; w++) d[w] = stash[(slot * 8 + w) * SMI_HASH_THREADS + tid];
     };
-    if (FROM_ELEMS) {
+    if (FROM_ELEMS && row_cols) {
+        // row leaves: leaf i = Hash::from_field_elements(row i) over row_cols columns row_stride apart
+        for (uint32_t i = 0; i < per; i += 2) {
+            uint32_t d0[8], d1[8];
+            if (row_cols <= 4 && i + 1 < per) {
+                uint32_t r0[4], r1[4];
+                for (uint32_t c = 0; c < 4; c++) {
+                    r0[c] = c < row_cols ? elems[c * row_stride + first + i] : 0u;
+                    r1[c] = c < row_cols ? elems[c * row_stride + first + i + 1] : 0u;
+                }
+                hashc::row_hash2(r0, r1, (int)row_cols, d0, d1);
+                put(nodes + 2 * (first + i), i, d0);
+                put(nodes + 2 * (first + i + 1), i + 1, d1);
+            } else {
+                for (uint32_t k = 0; k < 2 && i + k < per; k++) {
+                    uint32_t row[SMI_ROW_MAX];
+                    for (uint32_t c = 0; c < row_cols; c++) row[c] = elems[c * row_stride + first + i + k];
+                    hashc::row_hash(row, (int)row_cols, d0);
+                    put(nodes + 2 * (first + i + k), i + k, d0);
+                }
+            }
+        }
+    } else if (FROM_ELEMS) {
         for (uint32_t i = 0; i < per; i += 2) {
             uint32_t d0[8], d1[8];
             if (i + 1 < per) {
@@ -96,7 +120,7 @@ __global__ __launch_bounds__(SMI_HASH_THREADS) void merkle_sub_kernel(const uint
 template <bool FROM_ELEMS>
 __global__ __launch_bounds__(SMI_TOP_THREADS) void merkle_top_kernel(const uint32_t *__restrict__ elems, uint4 *nodes, size_t n,
                                                                       uint32_t lvl_in, uint32_t chunk, size_t elem_stride,
-                                                                      size_t node_stride) {
+                                                                      size_t node_stride, uint32_t row_cols, size_t row_stride) {
     __shared__ uint32_t buf[8 * SMI_TOP_MAX];
     elems += (size_t)blockIdx.y * elem_stride;
     nodes += (size_t)blockIdx.y * node_stride;
@@ -105,7 +129,13 @@ __global__ __launch_bounds__(SMI_TOP_THREADS) void merkle_top_kernel(const uint3
     uint32_t d[8];
     for (uint32_t i = tid; i < chunk; i += SMI_TOP_THREADS) {
         if (FROM_ELEMS) {
-            hashc::leaf_hash(elems[first + i], d);
+            if (row_cols) {
+                uint32_t row[SMI_ROW_MAX];
+                for (uint32_t c = 0; c < row_cols; c++) row[c] = elems[c * row_stride + first + i];
+                hashc::row_hash(row, (int)row_cols, d);
+            } else {
+                hashc::leaf_hash(elems[first + i], d);
+            }
             nodes[2 * (first + i)] = make_uint4(d[0], d[1], d[2], d[3]);
             nodes[2 * (first + i) + 1] = make_uint4(d[4], d[5], d[6], d[7]);
         } else {
@@ -236,14 +266,19 @@ static uint32_t log2_floor(size_t n) {
 // Builds levels (lvl_from, log2 n] of the tree in d_nodes; if d_elems != nullptr level 0 is
 // hashed from the codeword first (fused with the bottom levels).  n must be a power of two.
 int launch_merkle_batch(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_nodes, uint32_t n_trees, size_t elem_stride,
-                        size_t node_stride_bytes);
+                        size_t node_stride_bytes, uint32_t row_cols = 0, size_t row_stride = 0);
 int launch_merkle(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_nodes) {
     return launch_merkle_batch(ctx, d_elems, n, d_nodes, 1, 0, 0);
+}
+// one tree whose leaf i hashes row i of n_cols columns (column c at d_cols + c*col_stride)
+int launch_merkle_rows(smi_ctx *ctx, const uint32_t *d_cols, uint32_t n_cols, size_t col_stride, size_t n, uint8_t *d_nodes) {
+    if (!n_cols || n_cols > SMI_ROW_MAX) return smi_fail(ctx, SMI_ERR_BAD_ARG, "row leaves: 1..64 columns");
+    return launch_merkle_batch(ctx, d_cols, n, d_nodes, 1, 0, 0, n_cols, col_stride);
 }
 // n_trees equally sized trees in one set of launches: tree y reads d_elems + y*elem_stride and writes
 // d_nodes + y*node_stride_bytes.  The small upper levels of all trees share their launch latency.
 int launch_merkle_batch(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_nodes, uint32_t n_trees, size_t elem_stride,
-                        size_t node_stride_bytes) {
+                        size_t node_stride_bytes, uint32_t row_cols, size_t row_stride) {
     if (!n_trees) return SMI_OK;
     const size_t node_stride = node_stride_bytes / 16;
     const uint32_t depth = log2_floor(n);
@@ -261,7 +296,7 @@ int launch_merkle_batch(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t
         const char *e = getenv("SMI_MERKLE_TOP_BLOCKS");
         return (size_t)(e ? atoi(e) : 256);
     }();
-    if (from_elems && depth == 0) {
+    if (from_elems && depth == 0 && !row_cols) {
         for (uint32_t y = 0; y < n_trees; y++) SMI_TRY(launch_leaf_hash(ctx, d_elems + y * elem_stride, 1, d_nodes + y * node_stride_bytes));
         return SMI_OK;
     }
@@ -272,12 +307,12 @@ int launch_merkle_batch(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t
         const size_t n_chunks = count / chunk;
         if (n_chunks * n_trees <= TOP_BLOCKS) {
             const double hashed = (from_elems ? 2.0 * (double)count : (double)count) - (double)n_chunks;
-            ProfScope ps(ctx, "merkle_top_kernel", ((from_elems ? 4.0 : 32.0) * (double)count + 32.0 * hashed) * n_trees);
+            ProfScope ps(ctx, "merkle_top_kernel", ((from_elems ? 4.0 * (row_cols ? row_cols : 1) : 32.0) * (double)count + 32.0 * hashed) * n_trees);
             const dim3 grid((uint32_t)n_chunks, n_trees);
             if (from_elems)
-                merkle_top_kernel<true><<<grid, SMI_TOP_THREADS, 0, ctx->stream>>>(d_elems, nodes, n, 0, (uint32_t)chunk, elem_stride, node_stride);
+                merkle_top_kernel<true><<<grid, SMI_TOP_THREADS, 0, ctx->stream>>>(d_elems, nodes, n, 0, (uint32_t)chunk, elem_stride, node_stride, row_cols, row_stride);
             else
-                merkle_top_kernel<false><<<grid, SMI_TOP_THREADS, 0, ctx->stream>>>(nullptr, nodes, n, lvl, (uint32_t)chunk, 0, node_stride);
+                merkle_top_kernel<false><<<grid, SMI_TOP_THREADS, 0, ctx->stream>>>(nullptr, nodes, n, lvl, (uint32_t)chunk, 0, node_stride, 0, 0);
             HIP_TRY(ctx, hipGetLastError());
             from_elems = false;
             uint32_t up = 0;
@@ -292,12 +327,12 @@ int launch_merkle_batch(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t
         // algorithmic bytes: inputs read once (4 B elements or 32 B digests), every produced digest written once
         const double produced = from_elems ? (double)count * 2.0 - (double)(count >> K) : (double)count - (double)(count >> K);
         ProfScope ps(ctx, from_elems ? "merkle_sub_kernel<leaves>" : "merkle_sub_kernel<digests>",
-                     ((from_elems ? 4.0 : 32.0) * (double)count + 32.0 * produced) * n_trees);
+                     ((from_elems ? 4.0 * (row_cols ? row_cols : 1) : 32.0) * (double)count + 32.0 * produced) * n_trees);
         const dim3 grid(blocks_for(threads), n_trees);
         if (from_elems)
-            merkle_sub_kernel<true><<<grid, SMI_HASH_THREADS, lds, ctx->stream>>>(d_elems, nodes, n, 0, count, K, elem_stride, node_stride);
+            merkle_sub_kernel<true><<<grid, SMI_HASH_THREADS, lds, ctx->stream>>>(d_elems, nodes, n, 0, count, K, elem_stride, node_stride, row_cols, row_stride);
         else
-            merkle_sub_kernel<false><<<grid, SMI_HASH_THREADS, lds, ctx->stream>>>(nullptr, nodes, n, lvl, count, K, 0, node_stride);
+            merkle_sub_kernel<false><<<grid, SMI_HASH_THREADS, lds, ctx->stream>>>(nullptr, nodes, n, lvl, count, K, 0, node_stride, 0, 0);
         HIP_TRY(ctx, hipGetLastError());
         from_elems = false;
         lvl += K;

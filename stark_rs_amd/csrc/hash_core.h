@@ -265,6 +265,24 @@ SMI_HD void absorb32_words(uint32_t P[8], const uint32_t M[8]) {
     for (int j = 0; j < 8; j++) P[j] = V[j];
 }
 
+// A short last chunk of nw message words (nw even, < 8; the messages on this path are whole u64s):
+// bytes 0..4nw-1 go through the same recurrence, and the XORs they send seven places ahead land in
+// the untouched bytes 4nw .. 4nw+6 (never past byte 31, so nothing wraps onto bytes 0..6).
+SMI_HD void absorb_partial_words(uint32_t P[8], const uint32_t *M, int nw) {
+    uint32_t V[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        if (j >= nw) break;
+        uint32_t x = P[j];
+        if (j == 1) x ^= V[0] << 24;
+        if (j >= 2) x ^= funnel(V[j - 1], V[j - 2], 8);
+        V[j] = rotl3_bytes(add_bytes(x, M[j]));
+        P[j] = V[j];
+    }
+    P[nw] ^= nw >= 2 ? funnel(V[nw - 1], V[nw - 2], 8) : (V[0] << 24);   // bytes 4nw..4nw+3 ^= v_{4nw-7}..v_{4nw-4}
+    P[nw + 1] ^= V[nw - 1] >> 8;                                          // bytes 4nw+4..4nw+6 ^= v_{4nw-3}..v_{4nw-1}
+}
+
 // initial state in natural layout (src/hash.rs:10-12)
 struct InitWords {
     uint32_t p[8];
@@ -434,6 +452,60 @@ SMI_HD void node_hash2(const uint32_t l0[8], const uint32_t r0[8], const uint32_
     to_words2(st, X, Y);
     absorb32_words(X, r0);
     absorb32_words(Y, r1);
+    from_words2(X, Y, st);
+    mix2_t<false>(st);
+#pragma unroll 1
+    for (int k = 0; k < 8; k++) mix2_t<true>(st);
+    flush2(st);
+    to_words2(st, d0, d1);
+}
+
+// ---- row leaves: Hash::from_field_elements(&row) (src/hash.rs:32-35) for a trace row of W u32
+// residues, i.e. the 8W-byte message of their LE u64s.  W = 4 is exactly one 32-byte chunk (1 + 8
+// mixes, the cost of a single-element leaf); other widths take full chunks of four elements and a
+// short last chunk.  Build-defined leaf rule: the reference itself only ever
+// hashes one element per leaf (src/fri.rs:118-121).
+SMI_HD void row_chunk_words(const uint32_t *v, int count, uint32_t P[8]) {   // absorb `count` (1..4) elements into P
+    uint32_t M[8];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        M[2 * j] = j < count ? v[j] : 0u;
+        M[2 * j + 1] = 0u;
+    }
+    if (count == 4) absorb32_words(P, M);
+    else absorb_partial_words(P, M, 2 * count);
+}
+SMI_HD void row_hash(const uint32_t *v, int W, uint32_t d[8]) {
+    constexpr InitWords I = make_init_words();
+    uint32_t P[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) P[j] = I.p[j];
+    State st;
+    int done = 0;
+    bool first = true;
+    do {                                             // one pass per chunk (none for an empty row)
+        const int count = W - done < 4 ? W - done : 4;
+        if (count <= 0) break;
+        if (!first) to_words(st, P);
+        row_chunk_words(v + done, count, P);
+        from_words(P, st);
+        mix(st);
+        first = false;
+        done += count;
+    } while (done < W);
+    if (first) from_words(P, st);
+    for (int k = 0; k < 8; k++) mix(st);
+    to_words(st, d);
+}
+// two rows of W <= 4 elements at once (the Merkle kernels' fast path)
+SMI_HD void row_hash2(const uint32_t *v0, const uint32_t *v1, int W, uint32_t d0[8], uint32_t d1[8]) {
+    constexpr InitWords I = make_init_words();
+    uint32_t X[8], Y[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) X[j] = Y[j] = I.p[j];
+    row_chunk_words(v0, W, X);
+    row_chunk_words(v1, W, Y);
+    State2 st;
     from_words2(X, Y, st);
     mix2_t<false>(st);
 #pragma unroll 1

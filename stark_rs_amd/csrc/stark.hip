@@ -5,7 +5,9 @@
 // SURVEY 8(d) cfg5 specifies, entirely on the device:
 //   1. per-column iNTT on the trace domain + coset NTT on the blowup domain (ntt.hip);
 //   2. one Merkle tree per column, one element per leaf -- the reference's only leaf rule
-//      (src/fri.rs:118-121);
+//      (src/fri.rs:118-121); or, with cfg.row_leaves, one tree whose leaf i hashes row i of the
+//      extended trace (Hash::from_field_elements(&row), a build-defined variant: four columns are one
+//      32-byte chunk, so the commit costs a quarter);
 //   3. a fresh FiatShamir absorbs the column roots in order and draws one weight per column
 //      (src/fiat_shamir.rs:15-25); codeword = sum_c weight_c * column_c;
 //   4. Fri::prove semantics on that codeword (src/fri.rs:250-311), fresh FiatShamir as in the
@@ -16,7 +18,8 @@
 #include "internal.h"
 
 int launch_merkle_batch(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_nodes, uint32_t n_trees, size_t elem_stride,
-                        size_t node_stride_bytes);
+                        size_t node_stride_bytes, uint32_t row_cols = 0, size_t row_stride = 0);
+int launch_merkle_rows(smi_ctx *ctx, const uint32_t *d_cols, uint32_t n_cols, size_t col_stride, size_t n, uint8_t *d_nodes);
 int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, size_t len, bool do_query, bool reset_arena,
             smi_fri_run **run_out, std::vector<uint8_t> *proof_host, uint64_t *top_host, uint8_t *roots_host,
             uint64_t *alphas_host, uint64_t *last_host, size_t *last_len);
@@ -37,6 +40,19 @@ __global__ void fs_weights_kernel(const uint8_t *const *root_ptrs, uint32_t n, u
         hashc::to_words(ch, d);
         weights[c] = (uint64_t)d[0] | ((uint64_t)d[1] << 32);
     }
+}
+
+// row-leaf variant: a single root enters the transcript; weight c = FiatShamir::challenge of the
+// transcript root || c as LE u64 (absorb(root); absorb(c.to_le_bytes()); challenge() on a clone)
+__global__ void fs_row_weights_kernel(const uint8_t *root, uint32_t n, uint64_t *weights) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    uint8_t msg[40];
+    for (int i = 0; i < 32; i++) msg[i] = root[i];
+    for (int i = 0; i < 8; i++) msg[32 + i] = i < 4 ? (uint8_t)(c >> (8 * i)) : 0;
+    uint32_t d[8];
+    hashc::hash_bytes(msg, 40, d);
+    weights[c] = (uint64_t)d[0] | ((uint64_t)d[1] << 32);
 }
 
 // out[i] = sum_c (weights[c] mod p) * cols[c*stride + i]      HBM-bound: 4*(n_cols+1) B per element
@@ -76,6 +92,7 @@ int smi_dev_stark_prove(smi_ctx *ctx, const smi_stark_cfg *cfg, const uint32_t *
     if (log_N > ctx->fs.K)
         return smi_fail(ctx, ctx->fs.F.p == 998244353u ? SMI_ERR_ROOT_TOO_LARGE : SMI_ERR_UNSUPPORTED_PRIME, "LDE domain too large");
     const size_t N = (size_t)1 << log_N;
+    const uint32_t T = cfg->row_leaves ? 1u : W;   // trees (and roots entering the transcript)
     SMI_TRY(arena_reset(ctx));
     hipEvent_t ev[5];
     const bool timed = stage_ms != nullptr;
@@ -92,24 +109,29 @@ int smi_dev_stark_prove(smi_ctx *ctx, const smi_stark_cfg *cfg, const uint32_t *
     std::vector<const uint8_t *> rootp(W);
     // the W column trees sit back to back (stride 2N digests) so one set of launches builds them all
     const size_t tree_stride = 2 * N * 32;
-    uint8_t *tree_base = (uint8_t *)arena_alloc(ctx, tree_stride * W);
+    uint8_t *tree_base = (uint8_t *)arena_alloc(ctx, tree_stride * T);
     if (!tree_base) return smi_fail(ctx, SMI_ERR_OOM, "stark_prove: tree memory");
-    for (uint32_t c = 0; c < W; c++) {
+    for (uint32_t c = 0; c < T; c++) {
         trees[c] = tree_base + c * tree_stride;
         rootp[c] = trees[c] + (2 * N - 2) * 32;
     }
     mark(0);
     SMI_TRY(smi_dev_lde(ctx, d_trace_cols, W, cfg->log_n, cfg->log_blowup, cfg->trace_offset, cfg->lde_offset, d_lde));
     mark(1);
-    SMI_TRY(launch_merkle_batch(ctx, d_lde, N, tree_base, W, N, tree_stride));
+    if (cfg->row_leaves) SMI_TRY(launch_merkle_rows(ctx, d_lde, W, N, N, tree_base));
+    else SMI_TRY(launch_merkle_batch(ctx, d_lde, N, tree_base, W, N, tree_stride));
     mark(2);
-    HIP_TRY(ctx, hipMemcpyAsync(d_rootp, rootp.data(), sizeof(void *) * W, hipMemcpyHostToDevice, ctx->stream));
-    fs_weights_kernel<<<1, 64, 0, ctx->stream>>>(d_rootp, W, d_weights);
+    if (cfg->row_leaves) {
+        fs_row_weights_kernel<<<1, 64, 0, ctx->stream>>>(rootp[0], W, d_weights);
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(d_rootp, rootp.data(), sizeof(void *) * W, hipMemcpyHostToDevice, ctx->stream));
+        fs_weights_kernel<<<1, 64, 0, ctx->stream>>>(d_rootp, W, d_weights);
+    }
     HIP_TRY(ctx, hipGetLastError());
     SMI_TRY(smi_dev_combine_columns(ctx, d_lde, W, N, N, d_weights, d_cw));
     mark(3);
     if (column_roots)
-        for (uint32_t c = 0; c < W; c++)
+        for (uint32_t c = 0; c < T; c++)
             HIP_TRY(ctx, hipMemcpyAsync(column_roots + 32 * c, rootp[c], 32, hipMemcpyDeviceToHost, ctx->stream));
     smi_fri_cfg fc;
     fc.omega = h_root(ctx, log_N);

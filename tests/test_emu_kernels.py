@@ -121,3 +121,20 @@ def test_emulated_ntt_extreme_values_stay_in_range(emu, oracle, p, g, L):
         assert np.array_equal(_ntt(emu, p, g, vals, L, n, 1, 1), o.fast_intt(vals, w, 1, p))
         nin = n // 8
         assert np.array_equal(_ntt(emu, p, g, vals[:nin], L, nin, 0, 3), o.fast_coset_ntt(vals[:nin], n, w, 3, p))
+
+
+@pytest.mark.parametrize("W", [0, 1, 2, 3, 4, 5, 7, 8, 9])
+def test_emulated_row_leaf_hash(emu, oracle, W):
+    """Hash::from_field_elements(&row) for rows of W residues (hash_core.h row_hash / row_hash2):
+    full chunks of four elements, short last chunks, the empty row."""
+    o = oracle
+    rng = np.random.default_rng(W)
+    n = 21
+    v = rng.integers(0, P, (n, max(W, 1)), dtype=np.int64).astype(np.uint32)
+    if W:
+        v[0, :] = P - 1
+        v[1, :] = 0
+    out = np.zeros((n, 32), dtype=np.uint8)
+    emu.emu_row_hash(v.ctypes.data_as(C.c_void_p), C.c_size_t(n), C.c_int(W), out.ctypes.data_as(C.c_void_p))
+    for i in range(n):
+        assert bytes(out[i]) == o.hash_from_field_elements([int(x) for x in v[i, :W]])

@@ -120,6 +120,51 @@ def test_copy_probe_twins_run_and_leave_the_engine_intact(eng, oracle):
     eng.dev_free(d_out)
 
 
+@pytest.mark.parametrize("W", [1, 2, 3, 4, 5, 9])
+@pytest.mark.parametrize("logn", [0, 3, 9, 13])
+def test_row_leaf_tree_equals_oracle(eng, oracle, W, logn):
+    """smi_dev_merkle_build_rows: leaf i = Hash::from_field_elements(row i) (src/hash.rs:32-35 on a
+    whole row -- build-defined leaf rule), every level against the oracle's MerkleTree::new."""
+    o = oracle
+    n = 1 << logn
+    cols = np.stack([_vals(o, 90 + 7 * W + c, n) for c in range(W)])
+    cols[0, 0] = P - 1
+    d_cols = _upload(eng, cols)
+    d_nodes = eng.dev_alloc((2 * n - 1) * 32)
+    eng.dev_merkle_build_rows(d_cols, W, n, n, d_nodes)
+    got = eng.dev_download(d_nodes, (2 * n - 1) * 8).astype(np.uint32).view(np.uint8).reshape(-1, 32)
+    leaves = np.stack([np.frombuffer(o.hash_from_field_elements([int(cols[c, i]) for c in range(W)]), dtype=np.uint8) for i in range(n)])
+    want = o.merkle_new(leaves)
+    assert np.array_equal(got, want)
+    eng.dev_free(d_cols)
+    eng.dev_free(d_nodes)
+
+
+def test_stark_prove_row_leaves_variant(eng, oracle):
+    """dev_stark_prove with one row-leaf tree instead of a tree per column: the root is the oracle's
+    root over the rows of the extended trace, the weights follow the documented transcript
+    (root || c), and the oracle's Fri::verify accepts the proof of the combined codeword."""
+    o = oracle
+    logn, lb, W, t = 10, 3, 4, 8
+    n, N = 1 << logn, 1 << (logn + lb)
+    cols = np.stack([_vals(o, 0x5354524B00 + c, n) for c in range(W)])
+    d_trace = _upload(eng, cols)
+    res = eng.dev_stark_prove(d_trace, W, logn, lb, t, row_leaves=True)
+    w, Wn = o.ff_prim_nth_root(n), o.ff_prim_nth_root(N)
+    lde = np.stack([o.fast_coset_ntt(o.fast_intt(cols[c], w, 1), N, Wn, G) for c in range(W)])
+    leaves = np.stack([np.frombuffer(o.hash_from_field_elements([int(lde[c, i]) for c in range(W)]), dtype=np.uint8) for i in range(N)])
+    root = o.merkle_commit(leaves)
+    assert res["column_roots"].shape == (1, 32) and bytes(res["column_roots"][0]) == root
+    weights = [int.from_bytes(o.hash_from_bytes(root + c.to_bytes(8, "little"))[:8], "little") % P for c in range(W)]
+    cw = np.zeros(N, dtype=object)
+    for c in range(W):
+        cw = (cw + weights[c] * lde[c].astype(object)) % P
+    cfg = o.fri_cfg(Wn, G, N, 1 << lb, t)
+    want, want_top = o.fri_prove(cfg, np.array(cw, dtype=np.uint64))
+    assert res["proof"] == want and res["top_indices"] == want_top and o.fri_verify(cfg, res["proof"])
+    eng.dev_free(d_trace)
+
+
 def test_sharded_commit_backend_world1(eng, oracle):
     """stark_rs_amd/sharded.py with the HIP backend at world size 1 (the collectives are covered by
     the gloo test): subtree kernel, device transcript hash and the shard fold entry point."""
