@@ -128,6 +128,25 @@ def test_ntt_extreme_values_lazy_ranges(eng, eng2, oracle, which, logn):
         assert np.array_equal(e.coset_ntt(vals[: n // 8], logn, 3), o.fast_coset_ntt(vals[: n // 8], n, w, 3, p))
 
 
+@pytest.mark.parametrize("p,g,logs", [(754974721, 11, (10, 14, 21, 24)), (12289, 11, (3, 12)), (167772161, 3, (13, 20, 25))])
+def test_other_primes_run_the_same_kernels(oracle, p, g, logs):
+    """The modulus is a run-time parameter (any odd prime < 2^30 with two-adicity >= 12): a prime in
+    [2^29, 2^30) takes the 4p lazy range like the reference prime, smaller ones the 8p range, and a
+    14-bit prime exercises the bounds of the table sizes.  Parity against the p-generic oracle."""
+    import stark_rs_amd as s
+    o = oracle
+    e = s.Engine(p, g, 0)
+    try:
+        for logn in logs:
+            n = 1 << logn
+            w = o.ff_prim_nth_root_g(n, p, g)
+            vals = _vals(o, logn, n, p)
+            assert np.array_equal(e.intt(vals, 3), o.fast_intt(vals, w, 3, p))
+            assert np.array_equal(e.coset_ntt(vals[: max(1, n // 8)], logn, 3), o.fast_coset_ntt(vals[: max(1, n // 8)], n, w, 3, p))
+    finally:
+        e.close()
+
+
 def test_poly_scale(eng, oracle):
     o = oracle
     assert list(eng.poly_scale([1, 2, 3], 2)) == [1, 4, 12]          # mod.rs:439-456
