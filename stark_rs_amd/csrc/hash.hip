@@ -47,10 +47,11 @@ __global__ __launch_bounds__(SMI_HASH_THREADS) void merkle_sub_kernel(const uint
         for (int w = 0; w < 8; w++) d[w] = stash[(slot * 8 + w) * SMI_HASH_THREADS + tid];
     };
     if (FROM_ELEMS && row_cols) {
-        // row leaves: leaf i = Hash::from_field_elements(row i) over row_cols columns row_stride apart
+        // row leaves: leaf i = Hash::from_field_elements(row i) over row_cols <= 4 columns row_stride
+        // apart (wider rows are hashed by row_hash_kernel and enter as digests)
         for (uint32_t i = 0; i < per; i += 2) {
             uint32_t d0[8], d1[8];
-            if (row_cols <= 4 && i + 1 < per) {
+            if (i + 1 < per) {
                 uint32_t r0[4], r1[4];
                 for (uint32_t c = 0; c < 4; c++) {
                     r0[c] = c < row_cols ? elems[c * row_stride + first + i] : 0u;
@@ -59,13 +60,11 @@ __global__ __launch_bounds__(SMI_HASH_THREADS) void merkle_sub_kernel(const uint
                 hashc::row_hash2(r0, r1, (int)row_cols, d0, d1);
                 put(nodes + 2 * (first + i), i, d0);
                 put(nodes + 2 * (first + i + 1), i + 1, d1);
-            } else {
-                for (uint32_t k = 0; k < 2 && i + k < per; k++) {
-                    uint32_t row[SMI_ROW_MAX];
-                    for (uint32_t c = 0; c < row_cols; c++) row[c] = elems[c * row_stride + first + i + k];
-                    hashc::row_hash(row, (int)row_cols, d0);
-                    put(nodes + 2 * (first + i + k), i + k, d0);
-                }
+            } else {   // odd leaf of a level (K = 0 never happens here; kept for symmetry)
+                uint32_t r0[4];
+                for (uint32_t c = 0; c < 4; c++) r0[c] = c < row_cols ? elems[c * row_stride + first + i] : 0u;
+                hashc::row_hash(r0, (int)row_cols, d0);
+                put(nodes + 2 * (first + i), i, d0);
             }
         }
     } else if (FROM_ELEMS) {
@@ -130,8 +129,8 @@ __global__ __launch_bounds__(SMI_TOP_THREADS) void merkle_top_kernel(const uint3
     for (uint32_t i = tid; i < chunk; i += SMI_TOP_THREADS) {
         if (FROM_ELEMS) {
             if (row_cols) {
-                uint32_t row[SMI_ROW_MAX];
-                for (uint32_t c = 0; c < row_cols; c++) row[c] = elems[c * row_stride + first + i];
+                uint32_t row[4];
+                for (uint32_t c = 0; c < 4; c++) row[c] = c < row_cols ? elems[c * row_stride + first + i] : 0u;
                 hashc::row_hash(row, (int)row_cols, d);
             } else {
                 hashc::leaf_hash(elems[first + i], d);
@@ -170,6 +169,18 @@ __global__ __launch_bounds__(SMI_TOP_THREADS) void merkle_top_kernel(const uint3
         }
         __syncthreads();
     }
+}
+
+// digests of rows of any width (the fused kernels above take rows of up to 4 columns)
+__global__ __launch_bounds__(SMI_HASH_THREADS) void row_hash_kernel(const uint32_t *__restrict__ cols, uint32_t n_cols, size_t stride,
+                                                                      uint4 *out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * SMI_HASH_THREADS + threadIdx.x;
+    if (i >= n) return;
+    uint32_t row[SMI_ROW_MAX], d[8];
+    for (uint32_t c = 0; c < n_cols; c++) row[c] = cols[c * stride + i];
+    hashc::row_hash(row, (int)n_cols, d);
+    out[2 * i] = make_uint4(d[0], d[1], d[2], d[3]);
+    out[2 * i + 1] = make_uint4(d[4], d[5], d[6], d[7]);
 }
 
 // digests only (Hash::from_field_elements per element)
@@ -273,7 +284,10 @@ int launch_merkle(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_no
 // one tree whose leaf i hashes row i of n_cols columns (column c at d_cols + c*col_stride)
 int launch_merkle_rows(smi_ctx *ctx, const uint32_t *d_cols, uint32_t n_cols, size_t col_stride, size_t n, uint8_t *d_nodes) {
     if (!n_cols || n_cols > SMI_ROW_MAX) return smi_fail(ctx, SMI_ERR_BAD_ARG, "row leaves: 1..64 columns");
-    return launch_merkle_batch(ctx, d_cols, n, d_nodes, 1, 0, 0, n_cols, col_stride);
+    if (n_cols <= 4) return launch_merkle_batch(ctx, d_cols, n, d_nodes, 1, 0, 0, n_cols, col_stride);
+    row_hash_kernel<<<blocks_for(n), SMI_HASH_THREADS, 0, ctx->stream>>>(d_cols, n_cols, col_stride, (uint4 *)d_nodes, n);
+    HIP_TRY(ctx, hipGetLastError());
+    return launch_merkle_batch(ctx, nullptr, n, d_nodes, 1, 0, 0);
 }
 // n_trees equally sized trees in one set of launches: tree y reads d_elems + y*elem_stride and writes
 // d_nodes + y*node_stride_bytes.  The small upper levels of all trees share their launch latency.
