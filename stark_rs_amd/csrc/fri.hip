@@ -83,6 +83,7 @@ __global__ void fs_challenge_kernel(const FsState *fs, uint64_t *alpha_out) {
 __global__ __launch_bounds__(64) void sample_indices_kernel(const uint64_t *challenge, uint64_t size, uint64_t reduced_size,
                                                             uint32_t number, uint64_t *indices, uint64_t *reduced) {
     __shared__ uint64_t cand[64];
+    __shared__ uint64_t s_red[256];   // accepted reduced indices, mirrored in LDS: the acceptance loop is O(number^2) look-ups
     __shared__ uint32_t s_cnt;
     const uint32_t lane = threadIdx.x;
     // seed = hash of the 8 LE bytes of the (unreduced) challenge; every lane computes it (uniform)
@@ -121,10 +122,11 @@ __global__ __launch_bounds__(64) void sample_indices_kernel(const uint64_t *chal
             for (uint32_t k = 0; k < 64 && cnt < number; k++) {
                 const uint64_t index = cand[k], ri = index % reduced_size;
                 bool seen = false;
-                for (uint32_t j = 0; j < cnt; j++) seen |= reduced[j] == ri;
+                for (uint32_t j = 0; j < cnt; j++) seen |= (j < 256 ? s_red[j] : reduced[j]) == ri;
                 if (!seen) {
                     indices[cnt] = index;
                     reduced[cnt] = ri;
+                    if (cnt < 256) s_red[cnt] = ri;
                     cnt++;
                 }
             }
