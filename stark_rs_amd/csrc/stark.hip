@@ -25,14 +25,14 @@ int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, si
             uint64_t *alphas_host, uint64_t *last_host, size_t *last_len);
 
 // weights[c] = FiatShamir::challenge after absorbing roots[0..c] (unreduced u64)
-__global__ void fs_weights_kernel(const uint8_t *const *root_ptrs, uint32_t n, uint64_t *weights) {
+__global__ void fs_weights_kernel(const uint8_t *const *root_ptrs, uint32_t n, uint64_t *weights, uint32_t *roots_out) {
     if (threadIdx.x || blockIdx.x) return;
     hashc::State st;
     hashc::init(st);
     for (uint32_t c = 0; c < n; c++) {
         const uint32_t *root = (const uint32_t *)root_ptrs[c];
         uint32_t m[8];
-        for (int i = 0; i < 8; i++) m[i] = root[i];
+        for (int i = 0; i < 8; i++) roots_out[8 * c + i] = m[i] = root[i];   // gathered: one copy to the host
         hashc::absorb_chunk32(st, m);
         hashc::State ch = st;
         for (int k = 0; k < 8; k++) hashc::mix(ch);
@@ -44,11 +44,13 @@ __global__ void fs_weights_kernel(const uint8_t *const *root_ptrs, uint32_t n, u
 
 // row-leaf variant: a single root enters the transcript; weight c = FiatShamir::challenge of the
 // transcript root || c as LE u64 (absorb(root); absorb(c.to_le_bytes()); challenge() on a clone)
-__global__ void fs_row_weights_kernel(const uint8_t *root, uint32_t n, uint64_t *weights) {
+__global__ void fs_row_weights_kernel(const uint8_t *root, uint32_t n, uint64_t *weights, uint8_t *roots_out) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
     uint8_t msg[40];
     for (int i = 0; i < 32; i++) msg[i] = root[i];
+    if (c == 0)
+        for (int i = 0; i < 32; i++) roots_out[i] = msg[i];
     for (int i = 0; i < 8; i++) msg[32 + i] = i < 4 ? (uint8_t)(c >> (8 * i)) : 0;
     uint32_t d[8];
     hashc::hash_bytes(msg, 40, d);
@@ -121,18 +123,17 @@ int smi_dev_stark_prove(smi_ctx *ctx, const smi_stark_cfg *cfg, const uint32_t *
     if (cfg->row_leaves) SMI_TRY(launch_merkle_rows(ctx, d_lde, W, N, N, tree_base));
     else SMI_TRY(launch_merkle_batch(ctx, d_lde, N, tree_base, W, N, tree_stride));
     mark(2);
+    uint8_t *d_roots = (uint8_t *)arena_alloc(ctx, 32 * (size_t)T);
+    if (!d_roots) return smi_fail(ctx, SMI_ERR_OOM, "stark_prove: device memory");
     if (cfg->row_leaves) {
-        fs_row_weights_kernel<<<1, 64, 0, ctx->stream>>>(rootp[0], W, d_weights);
+        fs_row_weights_kernel<<<1, 64, 0, ctx->stream>>>(rootp[0], W, d_weights, d_roots);
     } else {
         HIP_TRY(ctx, hipMemcpyAsync(d_rootp, rootp.data(), sizeof(void *) * W, hipMemcpyHostToDevice, ctx->stream));
-        fs_weights_kernel<<<1, 64, 0, ctx->stream>>>(d_rootp, W, d_weights);
+        fs_weights_kernel<<<1, 64, 0, ctx->stream>>>(d_rootp, W, d_weights, (uint32_t *)d_roots);
     }
     HIP_TRY(ctx, hipGetLastError());
     SMI_TRY(smi_dev_combine_columns(ctx, d_lde, W, N, N, d_weights, d_cw));
     mark(3);
-    if (column_roots)
-        for (uint32_t c = 0; c < T; c++)
-            HIP_TRY(ctx, hipMemcpyAsync(column_roots + 32 * c, rootp[c], 32, hipMemcpyDeviceToHost, ctx->stream));
     smi_fri_cfg fc;
     fc.omega = h_root(ctx, log_N);
     fc.offset = cfg->lde_offset;
@@ -142,6 +143,10 @@ int smi_dev_stark_prove(smi_ctx *ctx, const smi_stark_cfg *cfg, const uint32_t *
     std::vector<uint8_t> bytes;
     SMI_TRY(fri_run(ctx, &fc, d_cw, N, true, false, nullptr, &bytes, top_indices, nullptr, nullptr, nullptr, nullptr));
     mark(4);
+    if (column_roots) {   // fri_run has synchronised; the arena (and d_roots) is intact until the next reset
+        HIP_TRY(ctx, hipMemcpyAsync(column_roots, d_roots, 32 * (size_t)T, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     if (timed) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         for (int i = 0; i < 4; i++) {
