@@ -16,6 +16,7 @@ all ranks per second.  Reported beside it in the same JSON line:
                    of the same trace, with per-stage HIP-event times; prove_row_leaves_ms: the same
                    with one row-leaf tree instead of the four column trees (a build-defined variant);
   * ntt_2p20    -- BASELINE configs[1]: 2^20-point forward+inverse on the reference prime;
+                   cfg3_2p20x4_blowup8: configs[2], LDE + Merkle commit of a 2^20 x 4 trace on it;
   * four_step   -- (N > 1) one 2^26-point NTT sharded over the N GPUs with the RCCL all-to-all.
 """
 import argparse
@@ -267,6 +268,18 @@ def main():
             dt = time.perf_counter() - t1
             result["ntt_2p20"] = {"field_elements_per_s": 2 * reps * (1 << 20) / dt, "us_per_transform": 1e6 * dt / (2 * reps),
                                   "prime": s.P_REF}
+            # ---- BASELINE configs[2]: 2^20-row x 4-column trace, LDE at blowup 8 + Merkle commit, on the
+            # reference prime (N = 2^23 is its largest domain); the stage times of the prove over it
+            try:
+                tr = torch.from_numpy(np.concatenate([(splitmix64(0x5354524B00 + c, 1 << 20) % np.uint64(s.P_REF)).astype(np.uint32)
+                                                      for c in range(N_COLS)]).view(np.int32)).to(dev)
+                for _ in range(2):
+                    e1.dev_stark_prove(tr.data_ptr(), N_COLS, 20, LOG_BLOWUP, N_TESTS)
+                r3 = e1.dev_stark_prove(tr.data_ptr(), N_COLS, 20, LOG_BLOWUP, N_TESTS, timed=True)
+                result["cfg3_2p20x4_blowup8"] = {"prime": s.P_REF, "lde_ms": r3["stage_ms"]["lde"], "commit_ms": r3["stage_ms"]["commit"],
+                                                 "prove_ms": sum(r3["stage_ms"].values())}
+            except Exception as e:
+                result["cfg3_error"] = str(e)
             e1.close()
 
         # ---- BASELINE configs[3]: 2^26-point four-step NTT sharded over the N GPUs
