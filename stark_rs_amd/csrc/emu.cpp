@@ -57,11 +57,16 @@ template <int LOGR, int LOGW, int KIND, int CAP> void emu_pass(const PassArgs &a
 
 struct EmuLauncher {
     void small(const SmallArgs &a, uint32_t batch) {
-        std::vector<uint32_t> buf(1u << a.L);
+        std::vector<uint32_t> buf((1u << a.L) + ((1u << a.L) >> 6) + 1);
+        std::vector<Tw2> twm(((1u << a.L) >> 1) + 1);
+        for (uint32_t tid = 0; tid < SMI_NTT_THREADS; tid++) NttSmall::load_tw(a, twm.data(), tid);
         for (uint32_t b = 0; b < batch; b++) {
             for (uint32_t tid = 0; tid < SMI_NTT_THREADS; tid++) NttSmall::load(a, b, buf.data(), tid);
-            for (uint32_t s = 0; s < a.L; s++)
-                for (uint32_t tid = 0; tid < SMI_NTT_THREADS; tid++) NttSmall::stage(a, s, buf.data(), tid);
+            uint32_t s = 0;
+            for (; s + 2 <= a.L; s += 2)
+                for (uint32_t tid = 0; tid < SMI_NTT_THREADS; tid++) NttSmall::stage4(a, s, buf.data(), twm.data(), tid);
+            if (s < a.L)
+                for (uint32_t tid = 0; tid < SMI_NTT_THREADS; tid++) NttSmall::stage(a, s, buf.data(), twm.data(), tid);
             for (uint32_t tid = 0; tid < SMI_NTT_THREADS; tid++) NttSmall::store(a, b, buf.data(), tid);
         }
     }

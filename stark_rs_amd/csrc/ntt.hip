@@ -84,12 +84,19 @@ __global__ __launch_bounds__(1 << (LOGR + LOGW - 4)) void ntt_copy_probe_kernel(
 }
 
 __global__ __launch_bounds__(SMI_NTT_THREADS) void ntt_small_kernel(const SmallArgs a) {
-    __shared__ uint32_t buf[SMI_TILE];
+    __shared__ uint32_t buf[SMI_TILE + SMI_TILE / 64];
+    __shared__ Tw2 twm[SMI_TILE / 2];
     const uint32_t tid = threadIdx.x, batch = blockIdx.x;
+    NttSmall::load_tw(a, twm, tid);
     NttSmall::load(a, batch, buf, tid);
     __syncthreads();
-    for (uint32_t s = 0; s < a.L; s++) {
-        NttSmall::stage(a, s, buf, tid);
+    uint32_t s = 0;
+    for (; s + 2 <= a.L; s += 2) {
+        NttSmall::stage4(a, s, buf, twm, tid);
+        __syncthreads();
+    }
+    if (s < a.L) {
+        NttSmall::stage(a, s, buf, twm, tid);
         __syncthreads();
     }
     NttSmall::store(a, batch, buf, tid);

@@ -43,7 +43,7 @@
 #define SMI_TILE_LOG 12          // smallest tile (and the size limit of the single-workgroup kernel)
 #define SMI_TILE (1u << SMI_TILE_LOG)
 #define SMI_NTT_THREADS 256      // threads of the small kernel; pass kernels use tile/16 threads
-#define SMI_TW_LOG 11            // in-tile twiddle table: w_2048^j
+#define SMI_TW_LOG 12            // table of w_4096^j as (w, Shoup quotient) pairs: lines of the pass kernels, the small kernel
 
 // A table twiddle in plain form with its Shoup quotient q = floor(w * 2^32 / p).
 struct alignas(8) Tw2 {
@@ -444,7 +444,9 @@ template <int LOGR, int LOGW, int KIND, int CAP> struct NttPass {
     }
 };
 
-// ---- small transforms (n <= 4096): one workgroup per column, radix-2 DIF in LDS --------
+// ---- small transforms (n <= 4096): one workgroup per column, radix-4 DIF stages in LDS (a radix-2
+// stage when log n is odd), twiddles w_n^j staged in LDS once per workgroup, bit-reversed read at
+// the store.  Latency-sized work: the pass kernels above take over from n = 8192.
 struct SmallArgs {
     const uint32_t *in;
     uint32_t *out;
@@ -455,36 +457,60 @@ struct SmallArgs {
     uint32_t L, n_in, flags;
 };
 struct NttSmall {
+    // LDS index of point i: one word of padding per 64, so that the bit-reversed read of the store
+    // (addresses 2^(L-6) apart across a wave) and the short-span stages spread over the banks
+    static SMI_HD uint32_t at(uint32_t i) { return i + (i >> 6); }
+    // twm[j] = w_n^j with its Shoup quotient, j < n/2 (a stride of the context's w_4096^j table)
+    static SMI_HD void load_tw(const SmallArgs &a, Tw2 *twm, uint32_t tid) {
+        const uint32_t half_n = (1u << a.L) >> 1;
+        for (uint32_t j = tid; j < half_n; j += SMI_NTT_THREADS) twm[j] = a.T.tw10[j << (SMI_TW_LOG - a.L)];
+    }
     static SMI_HD void load(const SmallArgs &a, uint32_t batch, uint32_t *buf, uint32_t tid) {
         const uint32_t n = 1u << a.L;
         const uint32_t *in = a.in + (uint64_t)batch * a.in_stride;
         for (uint32_t g = tid; g < n; g += SMI_NTT_THREADS) {
             uint32_t v = g < a.n_in ? in[g] : 0u;
             if ((a.flags & NTT_PRE_SCALE) && v) v = mont_mul(v, two_level(a.S.lo, a.S.hi, a.S.h, g, a.F), a.F);
-            buf[g] = v;
+            buf[at(g)] = v;
         }
     }
-    // stage s: butterflies of span half = n >> (s+1)
-    static SMI_HD void stage(const SmallArgs &a, uint32_t s, uint32_t *buf, uint32_t tid) {
+    // x*w mod p, canonical (Shoup product in [0,2p), one conditional subtraction)
+    static SMI_HD uint32_t mulw(uint32_t x, const Tw2 &w, uint32_t p) { return lz_canon(shoup_mul(x, w, p), p); }
+    // stages s and s+1 at once (spans h = n >> (s+1) and h/2): one radix-4 butterfly per 4 points
+    static SMI_HD void stage4(const SmallArgs &a, uint32_t s, uint32_t *buf, const Tw2 *twm, uint32_t tid) {
+        const uint32_t n = 1u << a.L, qlog = a.L - s - 2, q = 1u << qlog, p = a.F.p;   // q = h/2
+        for (uint32_t u = tid; u < n / 4; u += SMI_NTT_THREADS) {
+            const uint32_t blk = u >> qlog, pos = u & (q - 1);
+            const uint32_t i = (blk << (qlog + 2)) + pos;
+            const uint32_t x0 = buf[at(i)], x1 = buf[at(i + q)], x2 = buf[at(i + 2 * q)], x3 = buf[at(i + 3 * q)];
+            // stage s: (x0, x2) with w_2h^pos, (x1, x3) with w_2h^(pos + q)
+            const uint32_t a0 = fp_add(x0, x2, p), a1 = fp_add(x1, x3, p);
+            const uint32_t c0 = mulw(fp_sub(x0, x2, p), twm[pos << s], p);
+            const uint32_t c1 = mulw(fp_sub(x1, x3, p), twm[(pos + q) << s], p);
+            // stage s+1: (a0, a1) and (c0, c1) with w_h^pos
+            const Tw2 w = twm[pos << (s + 1)];
+            buf[at(i)] = fp_add(a0, a1, p);
+            buf[at(i + q)] = mulw(fp_sub(a0, a1, p), w, p);
+            buf[at(i + 2 * q)] = fp_add(c0, c1, p);
+            buf[at(i + 3 * q)] = mulw(fp_sub(c0, c1, p), w, p);
+        }
+    }
+    // a single stage s: butterflies of span half = n >> (s+1)
+    static SMI_HD void stage(const SmallArgs &a, uint32_t s, uint32_t *buf, const Tw2 *twm, uint32_t tid) {
         const uint32_t n = 1u << a.L, hlog = a.L - s - 1, half = 1u << hlog;
         for (uint32_t u = tid; u < n / 2; u += SMI_NTT_THREADS) {
             const uint32_t blk = u >> hlog, pos = u & (half - 1);
             const uint32_t i = (blk << (hlog + 1)) + pos, j = i + half;
-            const uint32_t x = buf[i], y = buf[j];
-            buf[i] = fp_add(x, y, a.F.p);
-            uint32_t d = fp_sub(x, y, a.F.p);
-            const uint32_t e = pos << (a.T.K - (hlog + 1));  // w_{2half}^pos
-            if (e) d = mont_mul(d, two_level(a.T.lo, a.T.hi, a.T.h, e, a.F), a.F);
-            buf[j] = d;
+            const uint32_t x = buf[at(i)], y = buf[at(j)];
+            buf[at(i)] = fp_add(x, y, a.F.p);
+            buf[at(j)] = mulw(fp_sub(x, y, a.F.p), twm[pos << s], a.F.p);
         }
     }
     static SMI_HD void store(const SmallArgs &a, uint32_t batch, const uint32_t *buf, uint32_t tid) {
         const uint32_t n = 1u << a.L;
         uint32_t *out = a.out + (uint64_t)batch * a.out_stride;
         for (uint32_t k = tid; k < n; k += SMI_NTT_THREADS) {
-            uint32_t loc = 0;
-            for (uint32_t i = 0; i < a.L; i++) loc |= ((k >> i) & 1u) << (a.L - 1 - i);
-            uint32_t v = buf[loc];
+            uint32_t v = buf[at(a.L ? bitrev32(k) >> (32u - a.L) : 0u)];
             if (a.flags & NTT_POST_SCALE) v = mont_mul(v, two_level(a.S.lo, a.S.hi, a.S.h, k, a.F), a.F);
             out[k] = v;
         }
