@@ -247,7 +247,7 @@ int dev_ntt(smi_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint32_t log_n,
         rq.q_plain = q;
         SMI_TRY(ctx_scale_tables(ctx, ninv, q, log_n, &rq.S));
     }
-    if (log_n > SMI_TILE_LOG) SMI_TRY(ctx_scratch(ctx, (size_t)batch << log_n, &rq.scratch));
+    if (ntt_make_plan(log_n, batch).np > 0) SMI_TRY(ctx_scratch(ctx, (size_t)batch << log_n, &rq.scratch));   // inter-pass buffer
     HipLauncher ln{ctx};
     ntt_run(ln, rq);
     if (ln.err != hipSuccess) return smi_hip_fail(ctx, ln.err, "ntt kernel launch");

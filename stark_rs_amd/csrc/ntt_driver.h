@@ -33,6 +33,7 @@ template <class Launcher> inline void ntt_run(Launcher &ln, const NttRequest &rq
         ln.small(a, rq.batch);
         return;
     }
+    if (!rq.scratch) abort();   // a multi-pass plan without its inter-pass buffer is a driver bug: never launch on it
     const uint64_t n = 1ull << rq.L;
     uint32_t consumed = 0;
     for (int p = 0; p < pl.np; p++) {

@@ -49,7 +49,9 @@ inline bool ntt_plan_valid(uint32_t L, const NttPlan &pl) {
 inline NttPlan ntt_make_plan(uint32_t L, uint32_t batch = 1) {
     NttPlan pl;
     memset(&pl, 0, sizeof pl);
-    if (L <= SMI_TILE_LOG) return pl;  // np = 0
+    // np = 0: the single-workgroup kernel; a large batch of 4096-point columns is better served by two
+    // passes of 64-point lines (measured: 4096 columns 112 -> see DESIGN.md)
+    if (L < SMI_TILE_LOG || (L == SMI_TILE_LOG && batch < 64)) return pl;
     // optional override for tuning: SMI_NTT_PLAN_<L>="10.2,10.2" (logr.logw per pass)
     char name[32];
     snprintf(name, sizeof name, "SMI_NTT_PLAN_%u", L);

@@ -138,3 +138,19 @@ def test_emulated_row_leaf_hash(emu, oracle, W):
     emu.emu_row_hash(v.ctypes.data_as(C.c_void_p), C.c_size_t(n), C.c_int(W), out.ctypes.data_as(C.c_void_p))
     for i in range(n):
         assert bytes(out[i]) == o.hash_from_field_elements([int(x) for x in v[i, :W]])
+
+
+def test_emulated_ntt_batched_4096_point_columns_use_pass_kernels(emu, oracle):
+    """64 or more columns of 4096 points go through two passes of 64-point lines instead of the
+    single-workgroup kernel (planner, ntt_host.h)."""
+    o = oracle
+    L, batch = 12, 64
+    n = 1 << L
+    w = o.ff_prim_nth_root(n)
+    cols = o.splitmix64(11, batch * n) % np.uint64(P)
+    got = _ntt(emu, P, G, cols, L, n, 1, 3, batch=batch).reshape(batch, n)
+    for c in (0, 1, 37, 63):
+        assert np.array_equal(got[c], o.fast_intt(cols[c * n:(c + 1) * n], w, 3))
+    got = _ntt(emu, P, G, cols, L, n, 0, 5, batch=batch).reshape(batch, n)
+    for c in (0, 63):
+        assert np.array_equal(got[c], o.fast_coset_ntt(cols[c * n:(c + 1) * n], n, w, 5))

@@ -147,6 +147,30 @@ def test_other_primes_run_the_same_kernels(oracle, p, g, logs):
         e.close()
 
 
+@pytest.mark.parametrize("batch", [1, 63, 64, 200])
+def test_batched_4096_point_columns(eng, oracle, batch):
+    """Columns of 4096 points: fewer than 64 go through the single-workgroup kernel, 64 or more
+    through two passes of 64-point lines (planner) -- same results either way."""
+    o = oracle
+    L = 12
+    n = 1 << L
+    w = o.ff_prim_nth_root(n)
+    cols = _vals(o, 500 + batch, batch * n)
+    d_in = eng.dev_alloc(batch * n * 4)
+    d_out = eng.dev_alloc(batch * n * 4)
+    eng.dev_upload(cols, d_in)
+    eng.dev_ntt(d_in, d_out, L, batch=batch, inverse=True, offset=3)
+    got = eng.dev_download(d_out, batch * n).reshape(batch, n)
+    for c in sorted({0, batch // 3, batch - 1}):
+        assert np.array_equal(got[c], o.fast_intt(cols[c * n:(c + 1) * n], w, 3))
+    eng.dev_ntt(d_in, d_out, L, batch=batch, offset=5)
+    got = eng.dev_download(d_out, batch * n).reshape(batch, n)
+    for c in sorted({0, batch - 1}):
+        assert np.array_equal(got[c], o.fast_coset_ntt(cols[c * n:(c + 1) * n], n, w, 5))
+    eng.dev_free(d_in)
+    eng.dev_free(d_out)
+
+
 def test_poly_scale(eng, oracle):
     o = oracle
     assert list(eng.poly_scale([1, 2, 3], 2)) == [1, 4, 12]          # mod.rs:439-456
