@@ -104,9 +104,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
     # Rehearsal knobs (one-GPU box): SMI_BENCH_BACKEND=gloo and SMI_BENCH_DEVICE=0 run N ranks on one
-    # card to exercise the distributed control flow; the driver's runs use neither.
+    # card to exercise the distributed control flow; SMI_BENCH_FORCE_DIST=1 runs the multi-GPU legs on
+    # a one-rank RCCL group (launched through torch.distributed.run).  The driver's runs use none.
+    distributed = world > 1 or os.environ.get("SMI_BENCH_FORCE_DIST") == "1"
     backend = os.environ.get("SMI_BENCH_BACKEND", "nccl")
     if "SMI_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["SMI_BENCH_DEVICE"])

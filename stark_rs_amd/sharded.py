@@ -80,6 +80,37 @@ class HipShardBackend:
         idx = torch.tensor(indices, dtype=torch.int64, device=cw.device)
         return [int(v) & 0xFFFFFFFF for v in cw[idx].cpu().tolist()]
 
+    def gather_many(self, reqs):
+        """[(block, tree, local indices)] -> [(values, paths)], a path being depth*32 bytes
+        (MerkleTree::open, src/merkle.rs:67-80): one index upload, one gather per tensor, one copy back."""
+        rows, spans, at = [], [], 0
+        for cw, tree, loc in reqs:
+            depth = tree.n.bit_length() - 1
+            spans.append((at, len(loc), depth))
+            i = np.asarray(loc, dtype=np.int64)
+            lv = np.arange(depth, dtype=np.int64)
+            rows += [i, ((2 * tree.n - ((2 * tree.n) >> lv))[None, :] + ((i[:, None] >> lv[None, :]) ^ 1)).reshape(-1)]
+            at += len(loc) * (1 + depth)
+        if not at:
+            return [([], []) for _ in reqs]
+        idx = torch.from_numpy(np.concatenate(rows)).to(self.dev)
+        pieces = []
+        for (cw, tree, loc), (at, k, depth) in zip(reqs, spans):
+            if not k:
+                continue
+            pieces.append(cw[idx[at:at + k]].view(torch.uint8))
+            if depth:
+                pieces.append(tree.nodes.view(-1, 32)[idx[at + k:at + k + k * depth]].reshape(-1))
+        flat = torch.cat(pieces).cpu().numpy()
+        out, at = [], 0
+        for (_cw, _tree, _loc), (_a, k, depth) in zip(reqs, spans):
+            vals = flat[at:at + 4 * k].view(np.uint32).tolist()
+            at += 4 * k
+            raw = flat[at:at + 32 * k * depth].tobytes()
+            at += 32 * k * depth
+            out.append((vals, [raw[32 * depth * j:32 * depth * (j + 1)] for j in range(k)]))
+        return out
+
     def hash_pairs(self, digests):
         """[2k x 32] digests -> [k x 32]: Hash::combine of adjacent pairs on the device."""
         return self.eng.hash_combine_pairs(np.ascontiguousarray(digests, dtype=np.uint8).reshape(-1, 32))
@@ -193,9 +224,10 @@ class ShardedFriCommit:
                 cw, sharded = self._all_gather(cw), False
             tree = self.b.subtree(cw)
             subs = self._gather_roots(tree.root) if sharded else None
-            root = bytes(top_levels(self.b, subs)[-1][0]) if sharded else tree.root
+            tops = top_levels(self.b, subs) if sharded else None
+            root = bytes(tops[-1][0]) if sharded else tree.root
             if keep:
-                self.rounds.append({"cw": cw, "tree": tree, "sharded": sharded, "length": length, "sub_roots": subs})
+                self.rounds.append({"cw": cw, "tree": tree, "sharded": sharded, "length": length, "sub_roots": subs, "top": tops})
             roots.append(root)
             transcript += root                                               # fiat_shamir.absorb, fri.rs:131
             if r == self.R - 1:
@@ -229,8 +261,9 @@ class ShardedFriProve(ShardedFriCommit):
         seed = self.b.hash_bytes(challenge.to_bytes(8, "little"))
         top = sample_indices(self.b.hash_bytes, seed, lens[1] if R > 1 else lens[0], lens[-1], t)
 
-        # what this rank owns of every (layer, a/b/c, test) opening
-        mine, indices = {}, list(top)
+        # what this rank owns of every (layer, a/b/c, test) opening, grouped by the round whose block
+        # and tree serve it (round r serves a and b of layer r and c of layer r-1)
+        want, indices = [[] for _ in range(R)], list(top)
         for i in range(R - 1):
             half = lens[i] // 2
             indices = [x % half for x in indices]                                   # src/fri.rs:283-286
@@ -238,16 +271,20 @@ class ShardedFriProve(ShardedFriCommit):
                 rd = self.rounds[rnd]
                 if rd["sharded"]:
                     blk = rd["length"] // G
-                    own = [(s_, j - g * blk) for s_, j in enumerate(idxs) if j // blk == g]
-                    upper = [bytes(lv[(g >> l) ^ 1]) for l, lv in enumerate(top_levels(self.b, rd["sub_roots"])[:-1])]
-                else:                                    # replicated round: rank 0 has everything
-                    own = list(enumerate(idxs)) if g == 0 else []
-                    upper = []
-                loc = [j for _, j in own]
-                vals = self.b.values(rd["cw"], loc)
-                paths = rd["tree"].open_many(loc)
-                for (s_, _), v, pth in zip(own, vals, paths):
-                    mine[(i, which, s_)] = (v, pth + upper)
+                    want[rnd] += [((i, which, s_), j - g * blk) for s_, j in enumerate(idxs) if j // blk == g]
+                elif g == 0:                             # replicated round: rank 0 has everything
+                    want[rnd] += [((i, which, s_), j) for s_, j in enumerate(idxs)]
+        reqs = [(rd["cw"], rd["tree"], [j for _, j in want[rnd]]) for rnd, rd in enumerate(self.rounds)]
+        if hasattr(self.b, "gather_many"):               # one device -> host copy for the whole query phase
+            res = self.b.gather_many(reqs)
+        else:
+            res = [(self.b.values(cw, loc), tree.open_many(loc)) for cw, tree, loc in reqs]
+        mine = {}                                        # key -> (value, path as depth*32 bytes)
+        for rnd, (vals, paths) in enumerate(res):
+            rd = self.rounds[rnd]
+            upper = b"".join(bytes(lv[(g >> l) ^ 1]) for l, lv in enumerate(rd["top"][:-1])) if rd["sharded"] else b""
+            for (key, _), v, pth in zip(want[rnd], vals, paths):
+                mine[key] = (v, (pth if isinstance(pth, (bytes, bytearray)) else b"".join(pth)) + upper)
         if G > 1:
             parts = [None] * G if g == 0 else None
             dist.gather_object(mine, parts, dst=0, group=self.group)
@@ -271,5 +308,5 @@ class ShardedFriProve(ShardedFriCommit):
             for s_ in range(t):                                                     # src/fri.rs:239-243
                 for w in "abc":
                     pth = got[(i, w, s_)][1]
-                    out += b"\x03" + u64(len(pth)) + b"".join(pth)
+                    out += b"\x03" + u64(len(pth) // 32) + pth
         return bytes(out), top
