@@ -1,4 +1,6 @@
 // api.hip -- context management and the extern "C" surface declared in include/stark_mi.h.
+#include <thread>
+
 #include "hash_core.h"
 #include "internal.h"
 
@@ -108,6 +110,10 @@ void smi_ctx_destroy(smi_ctx *ctx) {
     (void)hipFree(ctx->arena);
     for (void *q : ctx->arena_overflow) (void)hipFree(q);
     for (int i = 0; i < 4; i++) (void)hipFree(ctx->tmp[i]);
+    for (int i = 0; i < 2; i++) {
+        if (ctx->pin[i]) (void)hipHostFree(ctx->pin[i]);
+        if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]);
+    }
     (void)hipFree(ctx->d_flag);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -272,6 +278,109 @@ int check_flag(smi_ctx *ctx) {
     return SMI_OK;
 }
 
+// ---- large transfers between the caller's buffers and the device.  Field values cross the ABI as
+// u64 (the reference's wire width, src/stream.rs:45) in ordinary pageable memory, but a residue is 32
+// bits: only the u32 halves cross PCIe, by DMA into / out of two pinned chunks, while host threads
+// widen (or narrow and range-check) the previous chunk against the caller's buffer.  Small transfers
+// keep the plain path (one staged copy + a device kernel).
+static constexpr size_t SMI_PIN_CHUNK = (size_t)8 << 20;   // elements per pinned chunk (32 MiB)
+static constexpr size_t SMI_PIN_MIN = (size_t)1 << 20;     // below this many elements: plain path
+
+static int ctx_pinned(smi_ctx *ctx) {
+    for (int i = 0; i < 2; i++) {
+        if (!ctx->pin[i] && hipHostMalloc(&ctx->pin[i], SMI_PIN_CHUNK * 4, hipHostMallocDefault) != hipSuccess) {
+            ctx->pin[i] = nullptr;
+            return smi_fail(ctx, SMI_ERR_OOM, "hipHostMalloc");
+        }
+        if (!ctx->pin_ev[i]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->pin_ev[i], hipEventDisableTiming));
+    }
+    return SMI_OK;
+}
+template <class Fn> static void host_parallel(size_t n, Fn fn) {   // fn(lo, hi) over [0, n) on up to 8 threads
+    unsigned t = std::thread::hardware_concurrency();
+    t = t < 1 ? 1 : (t > 8 ? 8 : t);
+    if (n < ((size_t)1 << 18)) t = 1;
+    const size_t per = (n + t - 1) / t;
+    std::vector<std::thread> th;
+    for (unsigned i = 1; i < t; i++) {
+        const size_t lo = i * per, hi = lo + per < n ? lo + per : n;
+        if (lo < hi) th.emplace_back([=] { fn(lo, hi); });
+    }
+    fn(0, per < n ? per : n);
+    for (std::thread &x : th) x.join();
+}
+
+int dev_u32_to_host(smi_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t *host) {
+    if (!n) return SMI_OK;
+    if (n < SMI_PIN_MIN) {
+        void *stage;
+        SMI_TRY(ctx_tmp(ctx, 0, n * 8, &stage));
+        SMI_TRY(launch_widen(ctx, d_in, (uint64_t *)stage, n));
+        HIP_TRY(ctx, hipMemcpyAsync(host, stage, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return SMI_OK;
+    }
+    SMI_TRY(ctx_pinned(ctx));
+    const size_t nch = (n + SMI_PIN_CHUNK - 1) / SMI_PIN_CHUNK;
+    for (size_t c = 0; c <= nch; c++) {
+        if (c < nch) {   // chunk c leaves the device while chunk c-1 is widened below
+            const size_t off = c * SMI_PIN_CHUNK, cnt = n - off < SMI_PIN_CHUNK ? n - off : SMI_PIN_CHUNK;
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->pin[c & 1], d_in + off, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipEventRecord(ctx->pin_ev[c & 1], ctx->stream));
+        }
+        if (c > 0) {
+            const size_t off = (c - 1) * SMI_PIN_CHUNK, cnt = n - off < SMI_PIN_CHUNK ? n - off : SMI_PIN_CHUNK;
+            HIP_TRY(ctx, hipEventSynchronize(ctx->pin_ev[(c - 1) & 1]));
+            const uint32_t *src = (const uint32_t *)ctx->pin[(c - 1) & 1];
+            uint64_t *dst = host + off;
+            host_parallel(cnt, [=](size_t lo, size_t hi) {
+                for (size_t i = lo; i < hi; i++) dst[i] = src[i];
+            });
+        }
+    }
+    return SMI_OK;
+}
+
+int host_to_dev_u32(smi_ctx *ctx, const uint64_t *host, size_t n, uint32_t *d_out, int reduce) {
+    if (!n) return SMI_OK;
+    if (n < SMI_PIN_MIN) {
+        void *stage;
+        SMI_TRY(ctx_tmp(ctx, 0, n * 8, &stage));
+        HIP_TRY(ctx, hipMemcpyAsync(stage, host, n * 8, hipMemcpyHostToDevice, ctx->stream));
+        SMI_TRY(launch_narrow(ctx, (const uint64_t *)stage, d_out, n, reduce));
+        return check_flag(ctx);
+    }
+    SMI_TRY(ctx_pinned(ctx));
+    const uint64_t p = ctx->fs.F.p;
+    const size_t nch = (n + SMI_PIN_CHUNK - 1) / SMI_PIN_CHUNK;
+    std::vector<int> bad(nch, 0);
+    for (size_t c = 0; c < nch; c++) {
+        const size_t off = c * SMI_PIN_CHUNK, cnt = n - off < SMI_PIN_CHUNK ? n - off : SMI_PIN_CHUNK;
+        if (c >= 2) HIP_TRY(ctx, hipEventSynchronize(ctx->pin_ev[c & 1]));   // chunk c-2 has left this buffer
+        uint32_t *dst = (uint32_t *)ctx->pin[c & 1];
+        const uint64_t *src = host + off;
+        int *flag = &bad[c];
+        host_parallel(cnt, [=](size_t lo, size_t hi) {
+            uint64_t over = 0;
+            if (reduce) {
+                for (size_t i = lo; i < hi; i++) dst[i] = (uint32_t)(src[i] % p);
+            } else {
+                for (size_t i = lo; i < hi; i++) {
+                    over |= (uint64_t)(src[i] >= p);
+                    dst[i] = (uint32_t)src[i];
+                }
+            }
+            if (over) __atomic_store_n(flag, 1, __ATOMIC_RELAXED);
+        });
+        HIP_TRY(ctx, hipMemcpyAsync(d_out + off, dst, cnt * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->pin_ev[c & 1], ctx->stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t c = 0; c < nch; c++)
+        if (bad[c]) return smi_fail(ctx, SMI_ERR_NON_CANONICAL, "input field value >= p");
+    return SMI_OK;
+}
+
 // ------------------------------------------------------------------------- field scalars
 static bool is_pow2(uint64_t n) { return n && !(n & (n - 1)); }
 static uint32_t ilog2(uint64_t n) {
@@ -334,22 +443,11 @@ int smi_dev_free(smi_ctx *ctx, void *d_ptr) {
 }
 int smi_dev_upload_u64(smi_ctx *ctx, const uint64_t *host, size_t n, uint32_t *d_out, int reduce) {
     if (!ctx || (!host && n) || (!d_out && n)) return SMI_ERR_BAD_ARG;
-    if (!n) return SMI_OK;
-    void *stage;
-    SMI_TRY(ctx_tmp(ctx, 0, n * 8, &stage));
-    HIP_TRY(ctx, hipMemcpyAsync(stage, host, n * 8, hipMemcpyHostToDevice, ctx->stream));
-    SMI_TRY(launch_narrow(ctx, (const uint64_t *)stage, d_out, n, reduce));
-    return check_flag(ctx);
+    return host_to_dev_u32(ctx, host, n, d_out, reduce);
 }
 int smi_dev_download_u64(smi_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t *host) {
     if (!ctx || (!host && n) || (!d_in && n)) return SMI_ERR_BAD_ARG;
-    if (!n) return SMI_OK;
-    void *stage;
-    SMI_TRY(ctx_tmp(ctx, 0, n * 8, &stage));
-    SMI_TRY(launch_widen(ctx, d_in, (uint64_t *)stage, n));
-    HIP_TRY(ctx, hipMemcpyAsync(host, stage, n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return SMI_OK;
+    return dev_u32_to_host(ctx, d_in, n, host);
 }
 
 // ------------------------------------------------------------------------- univariate
@@ -376,18 +474,12 @@ int smi_dev_lde(smi_ctx *ctx, const uint32_t *d_cols, uint32_t n_cols, uint32_t 
 
 static int host_ntt(smi_ctx *ctx, const uint64_t *in, size_t n_in, uint64_t *out, uint32_t log_n, int inverse, uint64_t offset) {
     const size_t n = (size_t)1 << log_n;
-    void *stage, *d_in, *d_out;
-    SMI_TRY(ctx_tmp(ctx, 0, n * 8, &stage));
+    void *d_in, *d_out;
     SMI_TRY(ctx_tmp(ctx, 1, (n_in ? n_in : 1) * 4, &d_in));
     SMI_TRY(ctx_tmp(ctx, 2, n * 4, &d_out));
-    if (n_in) {
-        HIP_TRY(ctx, hipMemcpyAsync(stage, in, n_in * 8, hipMemcpyHostToDevice, ctx->stream));
-        SMI_TRY(launch_narrow(ctx, (const uint64_t *)stage, (uint32_t *)d_in, n_in, 0));
-    }
+    SMI_TRY(host_to_dev_u32(ctx, in, n_in, (uint32_t *)d_in, 0));
     SMI_TRY(dev_ntt(ctx, (const uint32_t *)d_in, (uint32_t *)d_out, log_n, n_in, 1, n_in, n, inverse, offset, 1));
-    SMI_TRY(launch_widen(ctx, (const uint32_t *)d_out, (uint64_t *)stage, n));
-    HIP_TRY(ctx, hipMemcpyAsync(out, stage, n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    return check_flag(ctx);
+    return dev_u32_to_host(ctx, (const uint32_t *)d_out, n, out);
 }
 
 int smi_intt(smi_ctx *ctx, const uint64_t *values, uint64_t *coeffs, uint32_t log_n, uint64_t offset) {
@@ -593,16 +685,12 @@ int smi_lde(smi_ctx *ctx, const uint64_t *cols, uint32_t n_cols, uint32_t log_n,
     if (log_n + log_blowup > ctx->fs.K)
         return smi_fail(ctx, ctx->fs.F.p == 998244353u ? SMI_ERR_ROOT_TOO_LARGE : SMI_ERR_UNSUPPORTED_PRIME, "LDE domain too large");
     const size_t n = (size_t)1 << log_n, N = n << log_blowup;
-    void *stage, *d_in, *d_out;
-    SMI_TRY(ctx_tmp(ctx, 0, (size_t)n_cols * N * 8, &stage));
+    void *d_in, *d_out;
     SMI_TRY(ctx_tmp(ctx, 1, (size_t)n_cols * n * 4, &d_in));
     SMI_TRY(ctx_tmp(ctx, 2, (size_t)n_cols * N * 4, &d_out));
-    HIP_TRY(ctx, hipMemcpyAsync(stage, cols, (size_t)n_cols * n * 8, hipMemcpyHostToDevice, ctx->stream));
-    SMI_TRY(launch_narrow(ctx, (const uint64_t *)stage, (uint32_t *)d_in, (size_t)n_cols * n, 0));
+    SMI_TRY(host_to_dev_u32(ctx, cols, (size_t)n_cols * n, (uint32_t *)d_in, 0));
     SMI_TRY(smi_dev_lde(ctx, (const uint32_t *)d_in, n_cols, log_n, log_blowup, trace_offset, lde_offset, (uint32_t *)d_out));
-    SMI_TRY(launch_widen(ctx, (const uint32_t *)d_out, (uint64_t *)stage, (size_t)n_cols * N));
-    HIP_TRY(ctx, hipMemcpyAsync(out, stage, (size_t)n_cols * N * 8, hipMemcpyDeviceToHost, ctx->stream));
-    return check_flag(ctx);
+    return dev_u32_to_host(ctx, (const uint32_t *)d_out, (size_t)n_cols * N, out);
 }
 
 // Trace::to_field_elements + get_col (src/trace.rs:21-34): row-major i128 -> column-major u64.

@@ -32,6 +32,8 @@ struct smi_ctx {
     void *tmp[4] = {nullptr, nullptr, nullptr, nullptr};  // staging buffers of the host-buffer entry points
     size_t tmp_bytes[4] = {0, 0, 0, 0};
     int *d_flag = nullptr;         // non-canonical input flag
+    void *pin[2] = {nullptr, nullptr};          // pinned chunks of the large host <-> device transfers
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
     std::string err;
     bool prof_on = false;
     bool copy_probe = false;       // smi_ctx_copy_probe: NTT passes launch their copy-only twins
@@ -108,3 +110,6 @@ int launch_widen(smi_ctx *ctx, const uint32_t *d_in, uint64_t *d_out, size_t n);
 int dev_ntt(smi_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint32_t log_n, size_t n_in, uint32_t batch,
             size_t in_stride, size_t out_stride, int inverse, uint64_t offset, uint64_t post_scale);
 int check_flag(smi_ctx *ctx);  // syncs; SMI_ERR_NON_CANONICAL if a narrow kernel saw a value >= p
+// caller's (pageable) u64 buffers <-> device u32 residues; synchronous on return
+int host_to_dev_u32(smi_ctx *ctx, const uint64_t *host, size_t n, uint32_t *d_out, int reduce);
+int dev_u32_to_host(smi_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t *host);

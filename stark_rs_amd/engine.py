@@ -141,10 +141,12 @@ class Engine:
         st = self.L.smi_domain_is_geometric(self.h, d.ctypes.data, len(d), C.byref(off))
         return (st == 0), off.value
 
-    def lde(self, cols, log_blowup, trace_offset=1, lde_offset=None):
+    def lde(self, cols, log_blowup, trace_offset=1, lde_offset=None, out=None):
         cols = _u64(cols)
         n_cols, n = cols.shape
-        out = np.empty((n_cols, n << log_blowup), dtype=np.uint64)
+        if out is None:
+            out = np.empty((n_cols, n << log_blowup), dtype=np.uint64)
+        assert out.dtype == np.uint64 and out.shape == (n_cols, n << log_blowup) and out.flags.c_contiguous
         lde_offset = self.g if lde_offset is None else lde_offset
         self._ck(self.L.smi_lde(self.h, cols.ctypes.data, n_cols, n.bit_length() - 1, log_blowup, trace_offset, lde_offset,
                                 out.ctypes.data))

@@ -258,6 +258,37 @@ def test_non_canonical_input_rejected(eng):
         eng.intt(v, 1)
 
 
+@pytest.mark.parametrize("n", [(1 << 20) + 12345, (1 << 24) + 77])
+def test_large_host_transfers_pinned_pipeline(eng, n):
+    """Transfers of 2^20 elements and more cross PCIe as u32 through two pinned chunks, widened /
+    narrowed and range-checked by host threads (api.hip): round trip over one, two and three chunks,
+    the reduce flag, and a value >= p in the last chunk."""
+    import stark_rs_amd as s
+    rng = np.random.default_rng(n)
+    v = rng.integers(0, P, n, dtype=np.uint64)
+    d = eng.dev_alloc(n * 4)
+    eng.dev_upload(v, d)
+    assert np.array_equal(eng.dev_download(d, n), v)
+    big = v + np.uint64(P) * rng.integers(0, 1 << 30, n, dtype=np.uint64)
+    eng.dev_upload(big, d, reduce=True)
+    assert np.array_equal(eng.dev_download(d, n), v)
+    bad = v.copy()
+    bad[n - 3] = P
+    with pytest.raises(s.StarkMiError, match="canonical"):
+        eng.dev_upload(bad, d)
+    eng.dev_upload(v, d)                      # the context stays usable after the rejection
+    assert np.array_equal(eng.dev_download(d, n), v)
+    eng.dev_free(d)
+
+
+def test_non_canonical_input_rejected_large(eng):
+    import stark_rs_amd as s
+    v = np.ones(1 << 20, dtype=np.uint64)
+    v[12345] = P + 1
+    with pytest.raises(s.StarkMiError, match="canonical"):
+        eng.intt(v, 1)
+
+
 # ------------------------------------------------------------------ hash / merkle
 def test_leaf_hashes(eng, oracle):
     o = oracle
