@@ -796,13 +796,11 @@ int smi_merkle_from_codeword(smi_ctx *ctx, const uint64_t *codeword, size_t n, s
     if (!ctx || !out || (n && !codeword)) return SMI_ERR_BAD_ARG;
     smi_tree *t = nullptr;
     SMI_TRY(tree_alloc(ctx, n, &t));
-    void *stage, *d_in;
-    int rc = ctx_tmp(ctx, 0, n * 8, &stage);
-    if (rc == SMI_OK) rc = ctx_tmp(ctx, 1, n * 4, &d_in);
-    if (rc == SMI_OK && hipMemcpyAsync(stage, codeword, n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = smi_fail(ctx, SMI_ERR_HIP, "upload codeword");
-    if (rc == SMI_OK) rc = launch_narrow(ctx, (const uint64_t *)stage, (uint32_t *)d_in, n, 0);
+    void *d_in;
+    int rc = ctx_tmp(ctx, 1, n * 4, &d_in);
+    if (rc == SMI_OK) rc = host_to_dev_u32(ctx, codeword, n, (uint32_t *)d_in, 0);
     if (rc == SMI_OK) rc = launch_merkle(ctx, (const uint32_t *)d_in, n, t->d_nodes);
-    if (rc == SMI_OK) rc = check_flag(ctx);
+    if (rc == SMI_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = smi_fail(ctx, SMI_ERR_HIP, "merkle build");
     if (rc != SMI_OK) {
         smi_merkle_free(t);
         return rc;

@@ -486,12 +486,8 @@ int smi_dev_fri_prove(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_co
 }
 
 static int upload_codeword(smi_ctx *ctx, const uint64_t *codeword, size_t len, uint32_t **d_cw) {
-    void *stage;
-    SMI_TRY(ctx_tmp(ctx, 0, len * 8, &stage));
     if (hipMalloc((void **)d_cw, len * 4 ? len * 4 : 4) != hipSuccess) return smi_fail(ctx, SMI_ERR_OOM, "hipMalloc codeword");
-    HIP_TRY(ctx, hipMemcpyAsync(stage, codeword, len * 8, hipMemcpyHostToDevice, ctx->stream));
-    SMI_TRY(launch_narrow(ctx, (const uint64_t *)stage, *d_cw, len, 0));
-    return check_flag(ctx);
+    return host_to_dev_u32(ctx, codeword, len, *d_cw, 0);
 }
 
 int smi_fri_prove(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint64_t *codeword, size_t len, uint8_t **proof,
@@ -530,16 +526,12 @@ int smi_fri_fold(smi_ctx *ctx, const uint64_t *codeword, size_t len, uint64_t al
                  uint64_t *out) {
     if (!ctx || !codeword || !out) return SMI_ERR_BAD_ARG;
     if (len < 2 || !is_pow2(len)) return smi_fail(ctx, SMI_ERR_BAD_ARG, "fold: codeword length must be a power of two >= 2");
-    void *stage, *d_in, *d_out, *d_alpha;
-    SMI_TRY(ctx_tmp(ctx, 0, len * 8, &stage));
+    void *d_in, *d_out, *d_alpha;
     SMI_TRY(ctx_tmp(ctx, 1, len * 4, &d_in));
     SMI_TRY(ctx_tmp(ctx, 2, len * 2 + 8, &d_out));
     SMI_TRY(ctx_tmp(ctx, 3, 8, &d_alpha));
-    HIP_TRY(ctx, hipMemcpyAsync(stage, codeword, len * 8, hipMemcpyHostToDevice, ctx->stream));
+    SMI_TRY(host_to_dev_u32(ctx, codeword, len, (uint32_t *)d_in, 0));
     HIP_TRY(ctx, hipMemcpyAsync(d_alpha, &alpha, 8, hipMemcpyHostToDevice, ctx->stream));
-    SMI_TRY(launch_narrow(ctx, (const uint64_t *)stage, (uint32_t *)d_in, len, 0));
     SMI_TRY(launch_fold(ctx, (const uint32_t *)d_in, len, (const uint64_t *)d_alpha, offset, omega, (uint32_t *)d_out));
-    SMI_TRY(launch_widen(ctx, (const uint32_t *)d_out, (uint64_t *)stage, len / 2));
-    HIP_TRY(ctx, hipMemcpyAsync(out, stage, (len / 2) * 8, hipMemcpyDeviceToHost, ctx->stream));
-    return check_flag(ctx);
+    return dev_u32_to_host(ctx, (const uint32_t *)d_out, len / 2, out);
 }
