@@ -126,8 +126,7 @@ extern "C" int emu_ntt(uint64_t p, uint64_t g, const uint32_t *in, uint32_t *out
     rq.in = in; rq.out = out; rq.scratch = scratch.data();
     rq.L = L; rq.n_in = n_in; rq.batch = batch; rq.in_stride = in_stride; rq.out_stride = out_stride; rq.F = F;
     EmuLauncher ln;
-    ntt_run(ln, rq);
-    return 0;
+    return ntt_run(ln, rq) ? 0 : -1;
 }
 
 // ---- hash phases (hash_core.h) --------------------------------------------------------

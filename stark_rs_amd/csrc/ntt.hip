@@ -249,7 +249,7 @@ int dev_ntt(smi_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint32_t log_n,
     }
     if (ntt_make_plan(log_n, batch).np > 0) SMI_TRY(ctx_scratch(ctx, (size_t)batch << log_n, &rq.scratch));   // inter-pass buffer
     HipLauncher ln{ctx};
-    ntt_run(ln, rq);
+    if (!ntt_run(ln, rq)) return smi_fail(ctx, SMI_ERR_BAD_ARG, "ntt: multi-pass plan without its inter-pass buffer");
     if (ln.err != hipSuccess) return smi_hip_fail(ctx, ln.err, "ntt kernel launch");
     return SMI_OK;
 }

@@ -7,7 +7,7 @@
 struct NttRequest {
     const uint32_t *in;
     uint32_t *out;
-    uint32_t *scratch;   // batch * 2^L elements, used when L > SMI_TILE_LOG
+    uint32_t *scratch;   // batch * 2^L elements, required whenever the plan has passes (ntt_make_plan(L, batch).np > 0)
     uint32_t L;
     uint32_t n_in;       // <= 2^L; inputs beyond it read as zero
     uint32_t batch;
@@ -23,7 +23,8 @@ struct NttRequest {
 // Launcher concept:
 //   void small(const SmallArgs&, uint32_t batch);
 //   void pass(int logr, int logw, bool last, const PassArgs&, uint32_t batch);
-template <class Launcher> inline void ntt_run(Launcher &ln, const NttRequest &rq) {
+// Returns false (and launches nothing) if a multi-pass plan comes without its inter-pass buffer.
+template <class Launcher> inline bool ntt_run(Launcher &ln, const NttRequest &rq) {
     const NttPlan pl = ntt_make_plan(rq.L, rq.batch);
     if (pl.np == 0) {
         SmallArgs a;
@@ -31,9 +32,9 @@ template <class Launcher> inline void ntt_run(Launcher &ln, const NttRequest &rq
         a.F = rq.F; a.T = rq.T; a.S = rq.S; a.L = rq.L; a.n_in = rq.n_in;
         a.flags = (rq.pre_scale ? NTT_PRE_SCALE : 0) | (rq.post_scale ? NTT_POST_SCALE : 0);
         ln.small(a, rq.batch);
-        return;
+        return true;
     }
-    if (!rq.scratch) abort();   // a multi-pass plan without its inter-pass buffer is a driver bug: never launch on it
+    if (!rq.scratch) return false;
     const uint64_t n = 1ull << rq.L;
     uint32_t consumed = 0;
     for (int p = 0; p < pl.np; p++) {
@@ -69,4 +70,5 @@ template <class Launcher> inline void ntt_run(Launcher &ln, const NttRequest &rq
         ln.pass(pl.logr[p], pl.logw[p], last, a, rq.batch);
         consumed += (uint32_t)pl.logr[p];
     }
+    return true;
 }
