@@ -321,7 +321,11 @@ def main():
             blk = (1 << logN) // world
             be = HipShardBackend(eng)
             block = be.tensor(splitmix64(9 + rank, blk) % np.uint64(p))
-            fc = ShardedFriCommit(be, p, eng.prim_nth_root(1 << logN), s.G2, 1 << logN, 1 << LOG_BLOWUP, N_TESTS, rank, world)
+            # blocks below 2^18 elements are gathered: from there a round is hash latency, not throughput,
+            # and one rank's tree costs less than the exchange
+            MIN_BLOCK = 1 << 18
+            fc = ShardedFriCommit(be, p, eng.prim_nth_root(1 << logN), s.G2, 1 << logN, 1 << LOG_BLOWUP, N_TESTS, rank, world,
+                                  min_block=MIN_BLOCK)
             fc.commit(block)
             torch.cuda.synchronize()
             barrier()
@@ -335,7 +339,8 @@ def main():
             result["sharded_fri_commit_2p25_ms"] = 1e3 * float(tt.item())
             # ... and the whole Fri::prove over it (owners open their leaves, rank 0 serializes)
             from stark_rs_amd.sharded import ShardedFriProve
-            fp = ShardedFriProve(be, p, eng.prim_nth_root(1 << logN), s.G2, 1 << logN, 1 << LOG_BLOWUP, N_TESTS, rank, world)
+            fp = ShardedFriProve(be, p, eng.prim_nth_root(1 << logN), s.G2, 1 << logN, 1 << LOG_BLOWUP, N_TESTS, rank, world,
+                                 min_block=MIN_BLOCK)
             fp.prove(block)
             torch.cuda.synchronize()
             barrier()
@@ -349,6 +354,25 @@ def main():
             result["sharded_fri_prove_2p25_ms"] = 1e3 * float(tt.item())
             if rank == 0:
                 result["sharded_fri_prove_bytes"] = len(proof)
+            # ... and BASELINE configs[4]: the full prove of ONE 2^22 x 4 trace over the N GPUs (strong
+            # scaling): LDE replicated, column trees and FRI sharded by blocks of leaves
+            from stark_rs_amd.sharded import ShardedStarkProve
+            one = torch.from_numpy(np.concatenate([(splitmix64(0x5354524B00 + c, n) % np.uint64(p)).astype(np.uint32)
+                                                   for c in range(N_COLS)]).view(np.int32)).to(dev)
+            sp = ShardedStarkProve(be, p, s.G2, LOG_ROWS, LOG_BLOWUP, N_COLS, N_TESTS, eng.prim_nth_root(1 << logN), rank, world,
+                                   min_block=MIN_BLOCK)
+            sp.prove(one)
+            torch.cuda.synchronize()
+            barrier()
+            t1 = time.perf_counter()
+            _roots, sproof, _top = sp.prove(one)
+            torch.cuda.synchronize()
+            barrier()
+            dt = time.perf_counter() - t1
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            result["sharded_prove_2p22x4_ms"] = {"value": 1e3 * float(tt.item()), "scaling": "strong",
+                                                 "proof_bytes": len(sproof) if rank == 0 else None}
           except Exception as e:
             import traceback
             result["sharded_fri_error"] = f"{type(e).__name__}: {e} | {traceback.format_exc(limit=3)}"

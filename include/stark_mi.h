@@ -153,6 +153,9 @@ int smi_hash_leaves(smi_ctx *ctx, const uint64_t *elems, size_t n, uint8_t *dige
 int smi_hash_combine_pairs(smi_ctx *ctx, const uint8_t *digests, size_t n_pairs, uint8_t *out);
 /* Hash::from_bytes (src/hash.rs:7-30) of one message (device single-lane kernel). */
 int smi_hash_bytes(smi_ctx *ctx, const uint8_t *msg, size_t len, uint8_t out[32]);
+/* The same for n messages of msg_len bytes each (msgs: n x msg_len, out: n x 32), one device lane
+ * per message: Fri::sample_indices hashes seed || counter for a run of counters (src/fri.rs:176-213). */
+int smi_hash_bytes_batch(smi_ctx *ctx, const uint8_t *msgs, size_t n, size_t msg_len, uint8_t *out);
 /* MerkleTree::commit (src/merkle.rs:44-65). */
 int smi_merkle_commit(smi_ctx *ctx, const uint8_t *leaves, size_t n, uint8_t root[32]);
 /* MerkleTree::new (src/merkle.rs:11-38); the tree (all levels) stays on the device. */

@@ -766,6 +766,21 @@ int smi_hash_bytes(smi_ctx *ctx, const uint8_t *msg, size_t len, uint8_t out[32]
     return SMI_OK;
 }
 
+int launch_hash_bytes_batch(smi_ctx *ctx, const uint8_t *d_msgs, size_t n, size_t len, uint32_t *d_out);
+int smi_hash_bytes_batch(smi_ctx *ctx, const uint8_t *msgs, size_t n, size_t msg_len, uint8_t *out) {
+    if (!ctx || (n && msg_len && !msgs) || (n && !out)) return SMI_ERR_BAD_ARG;
+    if (!n) return SMI_OK;
+    if (n > ((size_t)1 << 24) || msg_len > ((size_t)1 << 20)) return smi_fail(ctx, SMI_ERR_BAD_ARG, "hash_bytes_batch: at most 2^24 messages of 2^20 bytes");
+    void *d_in, *d_out;
+    SMI_TRY(ctx_tmp(ctx, 1, n * msg_len + 4, &d_in));
+    SMI_TRY(ctx_tmp(ctx, 2, n * 32, &d_out));
+    if (msg_len) HIP_TRY(ctx, hipMemcpyAsync(d_in, msgs, n * msg_len, hipMemcpyHostToDevice, ctx->stream));
+    SMI_TRY(launch_hash_bytes_batch(ctx, (const uint8_t *)d_in, n, msg_len, (uint32_t *)d_out));
+    HIP_TRY(ctx, hipMemcpyAsync(out, d_out, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SMI_OK;
+}
+
 static int tree_alloc(smi_ctx *ctx, size_t n, smi_tree **out) {
     if (n == 0) return smi_fail(ctx, SMI_ERR_EMPTY_LEAVES, nullptr);        // src/merkle.rs:12
     if (!is_pow2(n)) return smi_fail(ctx, SMI_ERR_LEAVES_NOT_POW2, nullptr);  // src/merkle.rs:13-16

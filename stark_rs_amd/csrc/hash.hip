@@ -239,6 +239,16 @@ __global__ void hash_bytes_kernel(const uint8_t *msg, size_t len, uint32_t *out)
     for (int i = 0; i < 8; i++) out[i] = d[i];
 }
 
+// n messages of the same length, one lane each (index sampling hashes seed || counter for a run
+// of counters, src/fri.rs:176-213)
+__global__ __launch_bounds__(64) void hash_bytes_batch_kernel(const uint8_t *msgs, size_t n, size_t len, uint32_t *out) {
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t d[8];
+    hashc::hash_bytes(msgs + i * len, len, d);
+    for (int k = 0; k < 8; k++) out[8 * i + k] = d[k];
+}
+
 // ------------------------------------------------------------------------- launches
 static inline uint32_t blocks_for(size_t threads) { return (uint32_t)((threads + SMI_HASH_THREADS - 1) / SMI_HASH_THREADS); }
 
@@ -264,6 +274,13 @@ int launch_verify_paths(smi_ctx *ctx, const uint8_t *d_leaves, const uint64_t *d
 }
 int launch_hash_bytes(smi_ctx *ctx, const uint8_t *d_msg, size_t len, uint32_t *d_out) {
     hash_bytes_kernel<<<1, 64, 0, ctx->stream>>>(d_msg, len, d_out);
+    HIP_TRY(ctx, hipGetLastError());
+    return SMI_OK;
+}
+
+int launch_hash_bytes_batch(smi_ctx *ctx, const uint8_t *d_msgs, size_t n, size_t len, uint32_t *d_out) {
+    if (!n) return SMI_OK;
+    hash_bytes_batch_kernel<<<(uint32_t)((n + 63) / 64), 64, 0, ctx->stream>>>(d_msgs, n, len, d_out);
     HIP_TRY(ctx, hipGetLastError());
     return SMI_OK;
 }

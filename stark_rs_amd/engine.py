@@ -176,6 +176,17 @@ class Engine:
         self._ck(self.L.smi_hash_bytes(self.h, msg, len(msg), out))
         return bytes(out)
 
+    def hash_bytes_batch(self, msgs):
+        """Hash::from_bytes of equally long messages -> list of 32-byte digests (one device call)."""
+        msgs = list(msgs)
+        if not msgs:
+            return []
+        ln = len(msgs[0])
+        assert all(len(m) == ln for m in msgs)
+        out = np.empty((len(msgs), 32), dtype=np.uint8)
+        self._ck(self.L.smi_hash_bytes_batch(self.h, b"".join(msgs), len(msgs), ln, out.ctypes.data))
+        return [bytes(r) for r in out]
+
     def merkle_commit(self, leaves) -> bytes:
         l = np.ascontiguousarray(leaves, dtype=np.uint8).reshape(-1, 32)
         out = (C.c_uint8 * 32)()

@@ -58,8 +58,14 @@ class HipShardBackend:
             self.n = cw.numel()
             self.nodes = torch.empty((2 * self.n - 1) * 32, dtype=torch.uint8, device=be.dev)
             be.eng.dev_merkle_build(cw.data_ptr(), self.n, self.nodes.data_ptr())
-            be.eng.sync()
-            self.root = bytes(self.nodes[-32:].cpu().numpy())
+            self.root_t = self.nodes[-32:]            # on the device: what the sub-root all-gather sends
+            self._root = None
+
+        @property
+        def root(self):
+            if self._root is None:
+                self._root = bytes(self.root_t.cpu().numpy())
+            return self._root
 
         def open_many(self, indices):
             """MerkleTree::open (src/merkle.rs:67-80) for a list of leaves: one device gather."""
@@ -111,12 +117,28 @@ class HipShardBackend:
             out.append((vals, [raw[32 * depth * j:32 * depth * (j + 1)] for j in range(k)]))
         return out
 
+    def lde(self, trace, n_cols, log_n, log_blowup, trace_offset, lde_offset):
+        """n_cols columns of 2^log_n residues (column-major) -> their extensions, column-major."""
+        out = torch.empty(n_cols << (log_n + log_blowup), dtype=torch.int32, device=self.dev)
+        self.eng.dev_lde(trace.data_ptr(), n_cols, log_n, log_blowup, out.data_ptr(), trace_offset, lde_offset)
+        return out
+
+    def combine(self, cols, n_cols, stride, start, length, weights):
+        """sum_c (weights[c] mod p) * cols[c*stride + start + i], i < length (unreduced u64 weights)."""
+        w = torch.tensor([x - (1 << 64) if x >= (1 << 63) else x for x in weights], dtype=torch.int64, device=self.dev)
+        out = torch.empty(length, dtype=torch.int32, device=self.dev)
+        self.eng.dev_combine_columns(cols.data_ptr() + 4 * start, n_cols, length, stride, w.data_ptr(), out.data_ptr())
+        return out
+
     def hash_pairs(self, digests):
         """[2k x 32] digests -> [k x 32]: Hash::combine of adjacent pairs on the device."""
         return self.eng.hash_combine_pairs(np.ascontiguousarray(digests, dtype=np.uint8).reshape(-1, 32))
 
     def hash_bytes(self, data):
         return self.eng.hash_bytes(data)
+
+    def hash_bytes_batch(self, msgs):
+        return self.eng.hash_bytes_batch(msgs)
 
     def fold(self, lo, hi, index0, full_len, alpha, offset, omega):
         out = torch.empty(lo.numel(), dtype=torch.int32, device=self.dev)
@@ -147,23 +169,46 @@ def top_levels(backend, sub_roots):
     return lv
 
 
+def gather_digests(backend, trees, world, group=None):
+    """All-gather of every rank's subtree roots (k x 32 bytes per rank) as one tensor collective;
+    -> [rank][k] bytes.  Roots that are still on the device travel from there (no host round trip)."""
+    if world == 1:
+        return [[t.root for t in trees]]
+    if all(hasattr(t, "root_t") for t in trees):
+        mine = torch.cat([t.root_t for t in trees])
+    else:
+        mine = torch.frombuffer(bytearray(b"".join(t.root for t in trees)), dtype=torch.uint8).clone()
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    backend.fence()
+    dist.all_gather(parts, mine, group=group)
+    flat = [bytes(p_.cpu().numpy()) for p_ in parts]
+    return [[f[32 * k:32 * (k + 1)] for k in range(len(trees))] for f in flat]
+
+
 def sample_index(digest, size):
     """src/fri.rs:168-174: a u128 accumulator shifted left by 8 per byte keeps, as usize, the last
     eight digest bytes big-endian."""
     return int.from_bytes(digest[-8:], "big") % size
 
 
-def sample_indices(hash_bytes, seed, size, reduced_size, number):
-    """src/fri.rs:176-213 (same asserts, same messages)."""
+def sample_indices(hash_bytes, seed, size, reduced_size, number, hash_batch=None):
+    """src/fri.rs:176-213 (same asserts, same messages).  hash_batch (optional) digests a run of
+    counters in one call; the accepted indices are the same either way."""
     assert number <= 2 * reduced_size, "not enough entropy in indices wrt last codeword"
     assert number <= reduced_size, "cannot sample more indices than available in last codeword"
-    indices, reduced, counter = [], [], 0
+    indices, reduced, counter, ready = [], set(), 0, []
     while len(indices) < number:
-        index = sample_index(hash_bytes(seed + counter.to_bytes(4, "little")), size)
+        if not ready:
+            if hash_batch is None:
+                ready = [hash_bytes(seed + counter.to_bytes(4, "little"))]
+            else:
+                run = max(2 * (number - len(indices)), 8)
+                ready = hash_batch([seed + (counter + k).to_bytes(4, "little") for k in range(run)])
+        index = sample_index(ready.pop(0), size)
         counter += 1
         if index % reduced_size not in reduced:
             indices.append(index)
-            reduced.append(index % reduced_size)
+            reduced.add(index % reduced_size)
     return indices
 
 
@@ -179,12 +224,8 @@ class ShardedFriCommit:
         self.rounds = []     # with keep=True: per round {cw, tree, sharded, length, sub_roots}
 
     # -- collectives ---------------------------------------------------------------------------
-    def _gather_roots(self, root):
-        if self.world == 1:
-            return [root]
-        out = [None] * self.world
-        dist.all_gather_object(out, root, group=self.group)     # G x 32 bytes
-        return out
+    def _gather_roots(self, tree):
+        return [r[0] for r in gather_digests(self.b, [tree], self.world, self.group)]
 
     def _exchange_halves(self, block):
         """Perfect shuffle: rank s sends the first half of its block to rank 2*(s mod G/2) and the
@@ -223,7 +264,7 @@ class ShardedFriCommit:
             if sharded and cw.numel() < self.min_block:
                 cw, sharded = self._all_gather(cw), False
             tree = self.b.subtree(cw)
-            subs = self._gather_roots(tree.root) if sharded else None
+            subs = self._gather_roots(tree) if sharded else None
             tops = top_levels(self.b, subs) if sharded else None
             root = bytes(tops[-1][0]) if sharded else tree.root
             if keep:
@@ -254,13 +295,19 @@ class ShardedFriProve(ShardedFriCommit):
     def prove(self, local_block):
         G, g, R, t = self.world, self.rank, self.R, self.t
         assert local_block.numel() * G == self.N, "initial codeword length does not match domain length"
+        import time as _time
+        marks = [("start", _time.perf_counter())]
+        mark = lambda name: marks.append((name, _time.perf_counter()))
         roots, _alphas, last = self.commit(local_block, keep=True)
+        mark("commit")
         lens = [self.N >> i for i in range(R)]
         # replicated: challenge after the last root (src/fri.rs:272), seed = Hash::from_u64(challenge).0
         challenge = int.from_bytes(self.b.hash_bytes(b"".join(roots))[:8], "little")
         seed = self.b.hash_bytes(challenge.to_bytes(8, "little"))
-        top = sample_indices(self.b.hash_bytes, seed, lens[1] if R > 1 else lens[0], lens[-1], t)
+        top = sample_indices(self.b.hash_bytes, seed, lens[1] if R > 1 else lens[0], lens[-1], t,
+                             getattr(self.b, "hash_bytes_batch", None))
 
+        mark("sample")
         # what this rank owns of every (layer, a/b/c, test) opening, grouped by the round whose block
         # and tree serve it (round r serves a and b of layer r and c of layer r-1)
         want, indices = [[] for _ in range(R)], list(top)
@@ -279,17 +326,21 @@ class ShardedFriProve(ShardedFriCommit):
             res = self.b.gather_many(reqs)
         else:
             res = [(self.b.values(cw, loc), tree.open_many(loc)) for cw, tree, loc in reqs]
+        mark("gather")
         mine = {}                                        # key -> (value, path as depth*32 bytes)
         for rnd, (vals, paths) in enumerate(res):
             rd = self.rounds[rnd]
             upper = b"".join(bytes(lv[(g >> l) ^ 1]) for l, lv in enumerate(rd["top"][:-1])) if rd["sharded"] else b""
             for (key, _), v, pth in zip(want[rnd], vals, paths):
                 mine[key] = (v, (pth if isinstance(pth, (bytes, bytearray)) else b"".join(pth)) + upper)
+        mark("assemble")
         if G > 1:
             parts = [None] * G if g == 0 else None
             dist.gather_object(mine, parts, dst=0, group=self.group)
         else:
             parts = [mine]
+        mark("collect")
+        self.stage_ms = {b: 1e3 * (tb - ta) for (_, ta), (b, tb) in zip(marks, marks[1:])}
         if g != 0:
             return None, top
 
@@ -309,4 +360,43 @@ class ShardedFriProve(ShardedFriCommit):
                 for w in "abc":
                     pth = got[(i, w, s_)][1]
                     out += b"\x03" + u64(len(pth) // 32) + pth
+        self.stage_ms["serialize"] = 1e3 * (_time.perf_counter() - marks[-1][1])
         return bytes(out), top
+
+
+class ShardedStarkProve:
+    """The build-defined prove of csrc/stark.hip (LDE -> one tree per column -> Fiat-Shamir weights ->
+    combined codeword -> Fri::prove) over G ranks, same column roots and proof bytes as one GPU.
+
+    The hashing is 85 % of the single-GPU prove and the LDE 6 %, so the LDE is *replicated* (every rank
+    extends all columns: no exchange, HBM-bound) and the hashing is *sharded*: rank g builds the
+    subtree over leaves [g*N/G, (g+1)*N/G) of every column, the G x W sub-roots are all-gathered
+    (G*W*32 bytes), the top log2 G levels and the transcript are replicated, every rank combines its own
+    block of the columns, and ShardedFriProve takes it from there.  Every rank calls prove(); rank 0
+    gets the proof bytes."""
+
+    def __init__(self, backend, p, g, log_n, log_blowup, n_cols, num_colinearity_tests, omega_N, rank=0, world=1, group=None,
+                 trace_offset=1, lde_offset=None, min_block=1 << 12):
+        self.b, self.p, self.rank, self.world, self.group = backend, p, rank, world, group
+        self.log_n, self.log_blowup, self.W = log_n, log_blowup, n_cols
+        self.trace_offset, self.lde_offset = trace_offset, g if lde_offset is None else lde_offset
+        self.N = 1 << (log_n + log_blowup)
+        assert world & (world - 1) == 0 and self.N % world == 0
+        self.fri = ShardedFriProve(backend, p, omega_N, self.lde_offset, self.N, 1 << log_blowup, num_colinearity_tests, rank, world,
+                                   group, min_block)
+
+    def prove(self, trace):
+        """trace: the W columns of 2^log_n residues, column-major, the same on every rank.
+        -> (column roots [W x bytes], proof bytes (rank 0) or None, top-level indices)."""
+        G, g, W, N = self.world, self.rank, self.W, self.N
+        blk = N // G
+        lde = self.b.lde(trace, W, self.log_n, self.log_blowup, self.trace_offset, self.lde_offset)
+        trees = [self.b.subtree(lde[c * N + g * blk:c * N + (g + 1) * blk]) for c in range(W)]
+        subs = gather_digests(self.b, trees, G, self.group)                 # G x W x 32 bytes
+        roots = [bytes(top_levels(self.b, [subs[r][c] for r in range(G)])[-1][0]) for c in range(W)]
+        # weight c = FiatShamir::challenge after absorbing roots[0..c] (csrc/stark.hip, fs_weights_kernel)
+        weights = [int.from_bytes(self.b.hash_bytes(b"".join(roots[:c + 1]))[:8], "little") for c in range(W)]
+        block = self.b.combine(lde, W, N, g * blk, blk, weights)
+        del trees                                                           # the column trees are not opened
+        proof, top = self.fri.prove(block)
+        return roots, proof, top

@@ -299,6 +299,18 @@ def test_leaf_hashes(eng, oracle):
     assert bytes(got[2]).hex() == "b41399e39a0d1249b4f0318e5e6416ccaa2dffb01519bf1296173be9c10b5f06"
 
 
+def test_hash_bytes_batch(eng, oracle):
+    """smi_hash_bytes_batch: one lane per message, same digests as Hash::from_bytes on each
+    (lengths around the 32-byte chunk boundary, the 36-byte seed || counter of index sampling)."""
+    o = oracle
+    rng = np.random.default_rng(11)
+    for ln, n in ((0, 3), (1, 5), (31, 70), (32, 64), (33, 65), (36, 200), (64, 9), (100, 130)):
+        msgs = [bytes(rng.integers(0, 256, ln, dtype=np.uint8)) for _ in range(n)]
+        got = eng.hash_bytes_batch(msgs)
+        assert got == [o.hash_from_bytes(m) for m in msgs], (ln, n)
+    assert eng.hash_bytes_batch([]) == []
+
+
 def test_combine_and_bytes(eng, oracle):
     o = oracle
     rng = np.random.default_rng(3)

@@ -165,6 +165,27 @@ def test_stark_prove_row_leaves_variant(eng, oracle):
     eng.dev_free(d_trace)
 
 
+@pytest.mark.parametrize("which", ["ref_prime", "second_prime"])
+def test_sharded_stark_prove_world1_equals_single_gpu_prove(eng, eng2, oracle, which):
+    """ShardedStarkProve with the HIP backend at world size 1 against smi_dev_stark_prove on the same
+    trace: same column roots, same proof bytes, same top-level indices (the multi-rank paths run over
+    gloo in tests/test_sharded_gloo.py)."""
+    from stark_rs_amd.sharded import HipShardBackend, ShardedStarkProve
+    o = oracle
+    e, p, g = (eng, P, G) if which == "ref_prime" else (eng2, P2, G2)
+    logn, lb, W, t = 12, 3, 4, 8
+    n, N = 1 << logn, 1 << (logn + lb)
+    cols = np.stack([_vals(o, 0x5354524B00 + c, n, p) for c in range(W)])
+    d = _upload(e, cols)
+    want = e.dev_stark_prove(d, W, logn, lb, t)
+    e.dev_free(d)
+    be = HipShardBackend(e)
+    sp = ShardedStarkProve(be, p, g, logn, lb, W, t, e.prim_nth_root(N))
+    roots, proof, top = sp.prove(be.tensor(cols.reshape(-1)))
+    assert roots == [bytes(r) for r in want["column_roots"]]
+    assert proof == want["proof"] and top == want["top_indices"]
+
+
 def test_sharded_commit_backend_world1(eng, oracle):
     """stark_rs_amd/sharded.py with the HIP backend at world size 1 (the collectives are covered by
     the gloo test): subtree kernel, device transcript hash and the shard fold entry point."""

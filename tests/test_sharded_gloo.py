@@ -71,6 +71,21 @@ class EmuShardBackend:
     def fence(self):
         pass
 
+    def lde(self, trace, n_cols, log_n, log_blowup, trace_offset, lde_offset):
+        from oracle import oracle as o
+        n, N = 1 << log_n, 1 << (log_n + log_blowup)
+        w, Wn = o.ff_prim_nth_root(n), o.ff_prim_nth_root(N)
+        cols = trace.numpy().view(np.uint32).astype(np.uint64).reshape(n_cols, n)
+        out = np.concatenate([o.fast_coset_ntt(o.fast_intt(cols[c], w, trace_offset), N, Wn, lde_offset) for c in range(n_cols)])
+        return self.tensor(out)
+
+    def combine(self, cols, n_cols, stride, start, length, weights):
+        v = cols.numpy().view(np.uint32).astype(object)
+        acc = np.zeros(length, dtype=object)
+        for c in range(n_cols):
+            acc = (acc + (weights[c] % self.p) * v[c * stride + start:c * stride + start + length]) % self.p
+        return self.tensor(acc.astype(np.uint64))
+
 
 def _worker(rank, world, port, logn, expansion, t, offset, min_block, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -116,6 +131,36 @@ def _prove_worker(rank, world, port, logn, expansion, t, offset, min_block, q):
     dist.destroy_process_group()
 
 
+def _stark_worker(rank, world, port, logn, lb, W, t, min_block, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from stark_rs_amd.sharded import ShardedStarkProve
+    from oracle import oracle as o
+    n, N = 1 << logn, 1 << (logn + lb)
+    w, Wn = o.ff_prim_nth_root(n), o.ff_prim_nth_root(N)
+    cols = np.stack([o.splitmix64(0x5354524B00 + c, n) % np.uint64(P) for c in range(W)])
+    be = EmuShardBackend(P, G)
+    sp = ShardedStarkProve(be, P, G, logn, lb, W, t, Wn, rank, world, min_block=min_block)
+    roots, proof, top = sp.prove(be.tensor(cols.reshape(-1)))
+    if rank == 0:
+        # the single-process composition, stage by stage (what tests/test_gpu_pipeline.py checks the
+        # one-GPU smi_dev_stark_prove against)
+        lde = [o.fast_coset_ntt(o.fast_intt(cols[c], w, 1), N, Wn, G) for c in range(W)]
+        fs, weights, want_roots = o.FiatShamir(), [], []
+        for c in range(W):
+            want_roots.append(o.merkle_commit(o.leaf_hashes(lde[c])))
+            fs.absorb(want_roots[-1])
+            weights.append(fs.challenge() % P)
+        cw = np.zeros(N, dtype=object)
+        for c in range(W):
+            cw = (cw + lde[c].astype(object) * weights[c]) % P
+        cfg = o.fri_cfg(Wn, G, N, 1 << lb, t)
+        want, want_top = o.fri_prove(cfg, cw.astype(np.uint64))
+        q.put(bool(roots == [bytes(r) for r in want_roots] and proof == want and top == want_top and o.fri_verify(cfg, proof)))
+    dist.destroy_process_group()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -154,6 +199,25 @@ def test_sharded_fri_prove_is_byte_identical_gloo(oracle, world, logn, expansion
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_prove_worker, args=(r, world, port, logn, expansion, t, offset, min_block, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(240)
+        assert pr.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+@pytest.mark.parametrize("world,logn,lb,W,t,min_block", [
+    (2, 8, 3, 4, 4, 64),        # column subtrees on two ranks, FRI sharded for a few rounds
+    (4, 7, 2, 3, 2, 16),        # three columns on four ranks: two levels above the sub-roots
+])
+def test_sharded_stark_prove_equals_single_process_composition_gloo(oracle, world, logn, lb, W, t, min_block):
+    """ShardedStarkProve (replicated LDE, sharded column trees and FRI): column roots, proof bytes and
+    top-level indices equal the single-process composition of csrc/stark.hip restated with the oracle."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stark_worker, args=(r, world, port, logn, lb, W, t, min_block, q)) for r in range(world)]
     for pr in procs:
         pr.start()
     for pr in procs:

@@ -33,7 +33,19 @@ def main():
     if rank == 0:
         want, wtop = eng.fri_prove(eng.fri_cfg(eng.prim_nth_root(N), s.G2, N, 8, 32), full.astype(np.uint64))
         ok = bytes(want) == proof and list(wtop) == top
-        print("sharded prove", "OK" if ok else "MISMATCH", len(proof), "bytes", flush=True)
+        print("sharded prove", "OK" if ok else "MISMATCH", len(proof), "bytes", {k: round(v, 2) for k, v in fp.stage_ms.items()}, flush=True)
+    # the whole build-defined prove (replicated LDE, sharded column trees + FRI) against one GPU's
+    from stark_rs_amd.sharded import ShardedStarkProve
+    logn, lb, W, t = logN - 3, 3, 4, 32
+    cols = np.concatenate([(splitmix64(0x5354524B00 + c, 1 << logn) % np.uint64(p)).astype(np.uint32) for c in range(W)])
+    trace = be.tensor(cols)
+    sp = ShardedStarkProve(be, p, s.G2, logn, lb, W, t, eng.prim_nth_root(N), rank, world)
+    for _ in range(2):
+        roots, proof, top = sp.prove(trace)
+    if rank == 0:
+        want = eng.dev_stark_prove(trace.data_ptr(), W, logn, lb, t)
+        ok = roots == [bytes(r) for r in want["column_roots"]] and proof == want["proof"] and top == want["top_indices"]
+        print("sharded stark prove", "OK" if ok else "MISMATCH", len(proof), "bytes", flush=True)
     dist.destroy_process_group()
 
 
