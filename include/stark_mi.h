@@ -237,6 +237,10 @@ int smi_dev_merkle_build(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_
 int smi_dev_merkle_build_rows(smi_ctx *ctx, const uint32_t *d_cols, uint32_t n_cols, size_t col_stride, size_t n, uint8_t *d_nodes);
 /* Tree over precomputed 32-byte leaves already at d_nodes[0 .. n*32). */
 int smi_dev_merkle_from_digests(smi_ctx *ctx, size_t n, uint8_t *d_nodes);
+/* Hash::from_bytes (src/hash.rs:7-30) of a message in device memory, digest to device memory: a
+ * transcript that lives on the device (roots in, the challenge = first 8 digest bytes out, see
+ * src/fiat_shamir.rs:19-25) needs no host round trip per round. */
+int smi_dev_hash_bytes(smi_ctx *ctx, const uint8_t *d_msg, size_t len, uint8_t *d_out32);
 /* Fri::fold_codeword with alpha read from device memory (*d_alpha: one unreduced u64). */
 int smi_dev_fri_fold(smi_ctx *ctx, const uint32_t *d_in, size_t len, const uint64_t *d_alpha, uint64_t offset,
                      uint64_t omega, uint32_t *d_out);

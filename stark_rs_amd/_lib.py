@@ -107,6 +107,7 @@ def lib():
         "smi_hash_combine_pairs": (i32, [vp, vp, sz, vp]),
         "smi_hash_bytes": (i32, [vp, C.c_char_p, sz, vp]),
         "smi_hash_bytes_batch": (i32, [vp, C.c_char_p, sz, sz, vp]),
+        "smi_dev_hash_bytes": (i32, [vp, vp, sz, vp]),
         "smi_merkle_commit": (i32, [vp, vp, sz, vp]),
         "smi_merkle_new": (i32, [vp, vp, sz, C.POINTER(vp)]),
         "smi_merkle_from_codeword": (i32, [vp, vp, sz, C.POINTER(vp)]),

@@ -766,6 +766,11 @@ int smi_hash_bytes(smi_ctx *ctx, const uint8_t *msg, size_t len, uint8_t out[32]
     return SMI_OK;
 }
 
+int smi_dev_hash_bytes(smi_ctx *ctx, const uint8_t *d_msg, size_t len, uint8_t *d_out32) {
+    if (!ctx || (len && !d_msg) || !d_out32) return SMI_ERR_BAD_ARG;
+    return launch_hash_bytes(ctx, d_msg, len, (uint32_t *)d_out32);
+}
+
 int launch_hash_bytes_batch(smi_ctx *ctx, const uint8_t *d_msgs, size_t n, size_t len, uint32_t *d_out);
 int smi_hash_bytes_batch(smi_ctx *ctx, const uint8_t *msgs, size_t n, size_t msg_len, uint8_t *out) {
     if (!ctx || (n && msg_len && !msgs) || (n && !out)) return SMI_ERR_BAD_ARG;

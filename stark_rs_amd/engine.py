@@ -307,6 +307,9 @@ class Engine:
         """One tree whose leaf i is Hash::from_field_elements(row i) over n_cols columns."""
         self._ck(self.L.smi_dev_merkle_build_rows(self.h, vp(d_cols), n_cols, col_stride, n, vp(d_nodes)))
 
+    def dev_hash_bytes(self, d_msg, length, d_out32):
+        self._ck(self.L.smi_dev_hash_bytes(self.h, vp(d_msg), length, vp(d_out32)))
+
     def dev_merkle_from_digests(self, n, d_nodes):
         self._ck(self.L.smi_dev_merkle_from_digests(self.h, n, vp(d_nodes)))
 

@@ -80,6 +80,60 @@ class HipShardBackend:
     def subtree(self, cw):
         return HipShardBackend.Tree(self, cw)
 
+    class Transcript:
+        """FiatShamir (src/fiat_shamir.rs:15-25) kept on the device: roots are copied in device to
+        device, a challenge is the digest of the transcript so far written to device memory (its first
+        8 bytes are the unreduced u64 the fold kernel reads) -- the round loop never waits for the host."""
+
+        def __init__(self, be, max_roots):
+            self.b, self.n, self.k = be, 0, 0
+            self.buf = torch.empty(max(max_roots, 1) * 32, dtype=torch.uint8, device=be.dev)
+            self.dig = torch.empty(max(max_roots, 1) * 32, dtype=torch.uint8, device=be.dev)
+
+        def absorb(self, node):                       # node: a Tree or TopTree (root on the device)
+            self.buf[32 * self.n:32 * self.n + 32].copy_(node.root_t)
+            self.n += 1
+
+        def challenge(self):                          # -> handle for fold(): 32 device bytes
+            out = self.dig[32 * self.k:32 * self.k + 32]
+            self.k += 1
+            self.b.eng.dev_hash_bytes(self.buf.data_ptr(), 32 * self.n, out.data_ptr())
+            return out
+
+        def roots(self):
+            flat = bytes(self.buf[:32 * self.n].cpu().numpy())
+            return [flat[32 * i:32 * i + 32] for i in range(self.n)]
+
+        def alphas(self):
+            d = self.dig[:32 * self.k].cpu().numpy().reshape(-1, 32)
+            return [int.from_bytes(bytes(r[:8]), "little") for r in d]
+
+        def weights(self):                            # the challenges so far as k unreduced u64 on the device
+            return self.dig[:32 * self.k].view(-1, 32)[:, :8].contiguous().view(torch.int64)
+
+    def transcript(self, max_roots):
+        return HipShardBackend.Transcript(self, max_roots)
+
+    class TopTree:
+        """The log2 G levels above the G sub-roots (replicated on every rank), built on the device."""
+
+        def __init__(self, be, digests_t):
+            self.G = digests_t.numel() // 32
+            self.nodes = torch.empty((2 * self.G - 1) * 32, dtype=torch.uint8, device=be.dev)
+            self.nodes[:self.G * 32].copy_(digests_t.reshape(-1))
+            be.eng.dev_merkle_from_digests(self.G, self.nodes.data_ptr())
+            self.root_t = self.nodes[-32:]
+
+        def levels(self):
+            flat, lv, off, k = self.nodes.cpu().numpy().reshape(-1, 32), [], 0, self.G
+            while k >= 1:
+                lv.append(flat[off:off + k])
+                off, k = off + k, k // 2
+            return lv
+
+    def top_tree(self, digests_t):
+        return HipShardBackend.TopTree(self, digests_t)
+
     def values(self, cw, indices):
         if not indices:
             return []
@@ -125,7 +179,8 @@ class HipShardBackend:
 
     def combine(self, cols, n_cols, stride, start, length, weights):
         """sum_c (weights[c] mod p) * cols[c*stride + start + i], i < length (unreduced u64 weights)."""
-        w = torch.tensor([x - (1 << 64) if x >= (1 << 63) else x for x in weights], dtype=torch.int64, device=self.dev)
+        w = weights if isinstance(weights, torch.Tensor) else torch.tensor(
+            [x - (1 << 64) if x >= (1 << 63) else x for x in weights], dtype=torch.int64, device=self.dev)
         out = torch.empty(length, dtype=torch.int32, device=self.dev)
         self.eng.dev_combine_columns(cols.data_ptr() + 4 * start, n_cols, length, stride, w.data_ptr(), out.data_ptr())
         return out
@@ -142,10 +197,10 @@ class HipShardBackend:
 
     def fold(self, lo, hi, index0, full_len, alpha, offset, omega):
         out = torch.empty(lo.numel(), dtype=torch.int32, device=self.dev)
-        a = torch.tensor([alpha - (1 << 64) if alpha >= (1 << 63) else alpha], dtype=torch.int64, device=self.dev)
+        a = alpha if isinstance(alpha, torch.Tensor) else torch.tensor(      # a Transcript challenge is already on the device
+            [alpha - (1 << 64) if alpha >= (1 << 63) else alpha], dtype=torch.int64, device=self.dev)
         self.eng.dev_fri_fold_shard(lo.data_ptr(), hi.data_ptr(), lo.numel(), index0, full_len, a.data_ptr(), offset, omega,
                                     out.data_ptr())
-        self.eng.sync()
         return out
 
     def fence(self):
@@ -169,20 +224,67 @@ def top_levels(backend, sub_roots):
     return lv
 
 
-def gather_digests(backend, trees, world, group=None):
-    """All-gather of every rank's subtree roots (k x 32 bytes per rank) as one tensor collective;
-    -> [rank][k] bytes.  Roots that are still on the device travel from there (no host round trip)."""
+class HostTranscript:
+    """FiatShamir on the host, for backends without a device transcript (the CPU backend of the
+    gloo tests): same interface as HipShardBackend.Transcript."""
+
+    def __init__(self, backend):
+        self.b, self._roots, self._alphas = backend, [], []
+
+    def absorb(self, node):
+        self._roots.append(node.root)                                         # fiat_shamir.absorb, fri.rs:131
+
+    def challenge(self):
+        a = int.from_bytes(self.b.hash_bytes(b"".join(self._roots))[:8], "little")   # fiat_shamir.rs:19-25, unreduced
+        self._alphas.append(a)
+        return a
+
+    def roots(self):
+        return list(self._roots)
+
+    def alphas(self):
+        return list(self._alphas)
+
+    def weights(self):
+        return list(self._alphas)
+
+
+class HostTopTree:
+    def __init__(self, backend, digests_t):
+        d = bytes(digests_t.cpu().numpy())
+        self._lv = top_levels(backend, [d[32 * i:32 * i + 32] for i in range(len(d) // 32)])
+        self.root = bytes(self._lv[-1][0])
+
+    def levels(self):
+        return self._lv
+
+
+def make_transcript(backend, max_roots):
+    return backend.transcript(max_roots) if hasattr(backend, "transcript") else HostTranscript(backend)
+
+
+def make_top_tree(backend, digests_t):
+    return backend.top_tree(digests_t) if hasattr(backend, "top_tree") else HostTopTree(backend, digests_t)
+
+
+def host_sync_needed(group=None):
+    """RCCL collectives are ordered with the engine's kernels by the stream they share; any other
+    backend (gloo in the tests and rehearsals) moves data on the host's schedule and needs the stream
+    drained around each collective."""
+    return dist.get_backend(group) != "nccl"
+
+
+def gather_digests_t(backend, nodes, world, group=None):
+    """All-gather of every rank's k subtree roots as one tensor collective -> uint8 tensor [G, k*32]
+    on the backend's device; roots that are still on the device travel from there."""
+    mine = torch.cat([n.root_t if hasattr(n, "root_t") else torch.frombuffer(bytearray(n.root), dtype=torch.uint8) for n in nodes])
     if world == 1:
-        return [[t.root for t in trees]]
-    if all(hasattr(t, "root_t") for t in trees):
-        mine = torch.cat([t.root_t for t in trees])
-    else:
-        mine = torch.frombuffer(bytearray(b"".join(t.root for t in trees)), dtype=torch.uint8).clone()
+        return mine.reshape(1, -1)
     parts = [torch.empty_like(mine) for _ in range(world)]
-    backend.fence()
+    if host_sync_needed(group):
+        backend.fence()
     dist.all_gather(parts, mine, group=group)
-    flat = [bytes(p_.cpu().numpy()) for p_ in parts]
-    return [[f[32 * k:32 * (k + 1)] for k in range(len(trees))] for f in flat]
+    return torch.stack(parts)
 
 
 def sample_index(digest, size):
@@ -221,12 +323,9 @@ class ShardedFriCommit:
         self.R = num_rounds(domain_length, expansion_factor, num_colinearity_tests)
         self.t = num_colinearity_tests
         self.min_block = max(min_block, 2)
-        self.rounds = []     # with keep=True: per round {cw, tree, sharded, length, sub_roots}
+        self.rounds = []     # with keep=True: per round {cw, tree, sharded, length, top}
 
     # -- collectives ---------------------------------------------------------------------------
-    def _gather_roots(self, tree):
-        return [r[0] for r in gather_digests(self.b, [tree], self.world, self.group)]
-
     def _exchange_halves(self, block):
         """Perfect shuffle: rank s sends the first half of its block to rank 2*(s mod G/2) and the
         second half to the next rank; receives `lo` from rank g//2 and `hi` from g//2 + G/2."""
@@ -236,17 +335,21 @@ class ShardedFriCommit:
         d0 = 2 * (g % (G // 2))
         in_split = [half if d in (d0, d0 + 1) else 0 for d in range(G)]
         out_split = [half if s in (g // 2, g // 2 + G // 2) else 0 for s in range(G)]
-        self.b.fence()
+        sync = host_sync_needed(self.group)
+        if sync:
+            self.b.fence()
         dist.all_to_all_single(recv, block, out_split, in_split, group=self.group)
-        if recv.is_cuda:
+        if sync and recv.is_cuda:
             torch.cuda.current_stream().synchronize()
         return recv[:half], recv[half:]        # ordered by source rank: lo (g//2) then hi (g//2 + G/2)
 
     def _all_gather(self, block):
         parts = [torch.empty_like(block) for _ in range(self.world)]
-        self.b.fence()
+        sync = host_sync_needed(self.group)
+        if sync:
+            self.b.fence()
         dist.all_gather(parts, block, group=self.group)
-        if block.is_cuda:
+        if sync and block.is_cuda:
             torch.cuda.current_stream().synchronize()
         return torch.cat(parts)
 
@@ -254,27 +357,26 @@ class ShardedFriCommit:
     def commit(self, local_block, keep=False):
         """local_block: this rank's contiguous block of the initial codeword (int32 tensor of u32
         residues).  Returns (roots [R x bytes], alphas [R-1 unreduced ints], last codeword tensor).
-        keep=True retains every round's local codeword block and tree for the query phase."""
+        keep=True retains every round's local codeword block and tree for the query phase.
+        With a device transcript (HIP backend) nothing in the loop waits for the host: roots and
+        challenges are read back once, after the last round."""
         G, g, p = self.world, self.rank, self.p
         cw, length, sharded = local_block, self.N, G > 1
         omega, offset = self.omega, self.offset
-        roots, alphas, transcript = [], [], b""
+        tr = make_transcript(self.b, self.R)
         self.rounds = []
         for r in range(self.R):
             if sharded and cw.numel() < self.min_block:
                 cw, sharded = self._all_gather(cw), False
             tree = self.b.subtree(cw)
-            subs = self._gather_roots(tree) if sharded else None
-            tops = top_levels(self.b, subs) if sharded else None
-            root = bytes(tops[-1][0]) if sharded else tree.root
+            # sharded: G sub-roots all-gathered (G x 32 bytes), the levels above them replicated
+            top = make_top_tree(self.b, gather_digests_t(self.b, [tree], G, self.group).reshape(-1)) if sharded else None
             if keep:
-                self.rounds.append({"cw": cw, "tree": tree, "sharded": sharded, "length": length, "sub_roots": subs, "top": tops})
-            roots.append(root)
-            transcript += root                                               # fiat_shamir.absorb, fri.rs:131
+                self.rounds.append({"cw": cw, "tree": tree, "sharded": sharded, "length": length, "top": top})
+            tr.absorb(top if sharded else tree)                              # fiat_shamir.absorb, fri.rs:131
             if r == self.R - 1:
                 break
-            alpha = int.from_bytes(self.b.hash_bytes(transcript)[:8], "little")   # fiat_shamir.rs:19-25, unreduced
-            alphas.append(alpha)
+            alpha = tr.challenge()                                           # fiat_shamir.rs:19-25, unreduced
             half = length // 2
             if sharded:
                 lo, hi = self._exchange_halves(cw)
@@ -285,7 +387,7 @@ class ShardedFriCommit:
             omega, offset = omega * omega % p, offset * offset % p             # fri.rs:146-147
         if sharded:
             cw = self._all_gather(cw)
-        return roots, alphas, cw
+        return tr.roots(), tr.alphas(), cw
 
 
 class ShardedFriProve(ShardedFriCommit):
@@ -330,7 +432,7 @@ class ShardedFriProve(ShardedFriCommit):
         mine = {}                                        # key -> (value, path as depth*32 bytes)
         for rnd, (vals, paths) in enumerate(res):
             rd = self.rounds[rnd]
-            upper = b"".join(bytes(lv[(g >> l) ^ 1]) for l, lv in enumerate(rd["top"][:-1])) if rd["sharded"] else b""
+            upper = b"".join(bytes(lv[(g >> l) ^ 1]) for l, lv in enumerate(rd["top"].levels()[:-1])) if rd["sharded"] else b""
             for (key, _), v, pth in zip(want[rnd], vals, paths):
                 mine[key] = (v, (pth if isinstance(pth, (bytes, bytearray)) else b"".join(pth)) + upper)
         mark("assemble")
@@ -392,11 +494,14 @@ class ShardedStarkProve:
         blk = N // G
         lde = self.b.lde(trace, W, self.log_n, self.log_blowup, self.trace_offset, self.lde_offset)
         trees = [self.b.subtree(lde[c * N + g * blk:c * N + (g + 1) * blk]) for c in range(W)]
-        subs = gather_digests(self.b, trees, G, self.group)                 # G x W x 32 bytes
-        roots = [bytes(top_levels(self.b, [subs[r][c] for r in range(G)])[-1][0]) for c in range(W)]
+        subs = gather_digests_t(self.b, trees, G, self.group) if G > 1 else None     # G x W x 32 bytes
         # weight c = FiatShamir::challenge after absorbing roots[0..c] (csrc/stark.hip, fs_weights_kernel)
-        weights = [int.from_bytes(self.b.hash_bytes(b"".join(roots[:c + 1]))[:8], "little") for c in range(W)]
-        block = self.b.combine(lde, W, N, g * blk, blk, weights)
+        tr = make_transcript(self.b, W)
+        for c in range(W):
+            tr.absorb(make_top_tree(self.b, subs[:, 32 * c:32 * c + 32].reshape(-1)) if G > 1 else trees[c])
+            tr.challenge()
+        block = self.b.combine(lde, W, N, g * blk, blk, tr.weights())
+        roots = tr.roots()
         del trees                                                           # the column trees are not opened
         proof, top = self.fri.prove(block)
         return roots, proof, top
