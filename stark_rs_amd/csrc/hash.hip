@@ -114,6 +114,9 @@ __global__ __launch_bounds__(SMI_HASH_THREADS) void merkle_sub_kernel(const uint
 // a barrier per level, the current level held in LDS as [word][slot].  grid.x = chunk, grid.y =
 // tree.  These levels are pure latency (one node hash deep each): as two-level launches of
 // merkle_sub_kernel they cost ~6.5 us per level, here one hash latency (~3.8 us).
+#ifndef SMI_TOP_UNROLL
+#define SMI_TOP_UNROLL 8   // closing mixes of a node hash scheduled together (see hashc::node_hash)
+#endif
 #define SMI_TOP_MAX 2048
 #define SMI_TOP_THREADS (SMI_TOP_MAX / 2)
 template <bool FROM_ELEMS>
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(SMI_TOP_THREADS) void merkle_top_kernel(const uint3
                 l[w] = buf[w * SMI_TOP_MAX + 2 * tid];
                 r[w] = buf[w * SMI_TOP_MAX + 2 * tid + 1];
             }
-            hashc::node_hash(l, r, d);
+            hashc::node_hash<SMI_TOP_UNROLL>(l, r, d);
             uint4 *dst = nodes + 2 * (level_offset(n, lvl) + (first >> (lvl - lvl_in)) + tid);
             dst[0] = make_uint4(d[0], d[1], d[2], d[3]);
             dst[1] = make_uint4(d[4], d[5], d[6], d[7]);

@@ -332,8 +332,11 @@ SMI_HD void leaf_hash(uint32_t v, uint32_t d[8]) {
     to_words(st, d);
 }
 
-// Hash::combine (src/hash.rs:41-46): 64 bytes = two chunks, 2 + 8 mixes.
-SMI_HD void node_hash(const uint32_t l[8], const uint32_t r[8], uint32_t d[8]) {
+// Hash::combine (src/hash.rs:41-46): 64 bytes = two chunks, 2 + 8 mixes.  UNROLL: how many of the 8
+// closing mixes the compiler may schedule together -- 1 where the kernel is bound by VALU issue (code
+// size, registers), more where a single wave per SIMD waits on the ring add's dependent chain and
+// the next mix's S-boxes can start under it (merkle_top_kernel).
+template <int UNROLL = 1> SMI_HD void node_hash(const uint32_t l[8], const uint32_t r[8], uint32_t d[8]) {
     constexpr InitWords I = make_init_words();
     uint32_t P[8];
 #pragma unroll
@@ -346,7 +349,7 @@ SMI_HD void node_hash(const uint32_t l[8], const uint32_t r[8], uint32_t d[8]) {
     absorb32_words(P, r);
     from_words(P, st);
     mix_t<false>(st);
-#pragma unroll 1
+#pragma unroll UNROLL
     for (int k = 0; k < 8; k++) mix_t<true>(st);
     flush(st);
     to_words(st, d);
