@@ -311,6 +311,27 @@ def test_hash_bytes_batch(eng, oracle):
     assert eng.hash_bytes_batch([]) == []
 
 
+def test_dev_hash_bytes_transcript_on_device(eng, oracle):
+    """smi_dev_hash_bytes: message and digest in device memory (the device-resident Fiat-Shamir
+    transcript of stark_rs_amd/sharded.py): digest of every prefix of a run of roots equals
+    Hash::from_bytes, and its first 8 bytes are FiatShamir::challenge (src/fiat_shamir.rs:19-25)."""
+    import torch
+    o = oracle
+    rng = np.random.default_rng(21)
+    roots = rng.integers(0, 256, 18 * 32, dtype=np.uint8)
+    buf = torch.from_numpy(roots).cuda()
+    out = torch.empty(32, dtype=torch.uint8, device="cuda")
+    for k in range(19):
+        eng.dev_hash_bytes(buf.data_ptr(), 32 * k, out.data_ptr())
+        eng.sync()
+        want = o.hash_from_bytes(bytes(roots[:32 * k]))
+        got = bytes(out.cpu().numpy())
+        assert got == want, k
+        fs = o.FiatShamir()
+        fs.absorb(bytes(roots[:32 * k]))
+        assert int.from_bytes(got[:8], "little") == fs.challenge()
+
+
 def test_combine_and_bytes(eng, oracle):
     o = oracle
     rng = np.random.default_rng(3)
