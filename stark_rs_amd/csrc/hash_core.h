@@ -84,6 +84,27 @@ SMI_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
     return a ^ b ^ c;
 #endif
 }
+// The inline-asm forms above are opaque to the optimizer.  Where every input of an S-box tail or of a
+// linear-mix XOR is a compile-time constant (the half of a leaf's state the 8-byte message never
+// reaches, in its first mix) these wrappers take the plain C expression instead, which folds away.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SMI_CONST_P(x) __builtin_constant_p(x)
+#else
+#define SMI_CONST_P(x) 0
+#endif
+SMI_HD uint32_t sbox_tail(uint32_t t, uint32_t kFE) {          // (t & 0xFE) | (t >> 8 & 1) per lane (dirt above bit 7 stays)
+    if (SMI_CONST_P(t)) return (t & 0x00FE00FEu) | ((t >> 8) & 0xFF01FF01u);
+    return bfi32(kFE, t, t >> 8);
+}
+SMI_HD uint32_t lin_sum(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3, uint32_t k63) {   // t0^t1^t2^t3 ^ 0x63 per lane
+    if (SMI_CONST_P(t0) && SMI_CONST_P(t1) && SMI_CONST_P(t2) && SMI_CONST_P(t3)) return t0 ^ t1 ^ t2 ^ t3 ^ 0x00630063u;
+    return xor3(xor3(t0, t1, t2), t3, k63);
+}
+SMI_HD uint32_t lin_out(uint32_t T, uint32_t t, uint32_t kFF) {   // (T ^ t), lanes masked clean
+    if (SMI_CONST_P(T) && SMI_CONST_P(t)) return (T ^ t) & 0x00FF00FFu;
+    return (T ^ t) & kFF;
+}
+
 // v_add3_u32 costs what two v_add_u32 cost (4 cycles per wave either way), so the choice is left
 // to the compiler: it keeps s[w] + s[w+1] off the dependent chain of the ring add.
 SMI_HD uint32_t add3(uint32_t a, uint32_t b, uint32_t c) { return a + (b + c); }
@@ -160,18 +181,18 @@ template <bool PENDING> SMI_HD void mix_t(State &st) {
 #pragma unroll
     for (int w = 0; w < 16; w++) {
         const uint32_t t = pk_mad_u16(s[w], 0x01F601F6u, PENDING ? C.rc502[w] : 0u);
-        r[w] = bfi32(kFE, t, t >> 8);
+        r[w] = sbox_tail(t, kFE);
     }
     // (2) linear mix: new = (t0^t1^t2^t3) ^ {t2, t1, t3, t0}, with the deferred ^0x63 (it passes
     // through the three-byte XORs unchanged); the final XOR also masks the lanes clean.
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const uint32_t t0 = r[4 * q], t1 = r[4 * q + 1], t2 = r[4 * q + 2], t3 = r[4 * q + 3];
-        const uint32_t T = xor3(xor3(t0, t1, t2), t3, k63);
-        s[4 * q] = (T ^ t2) & kFF;
-        s[4 * q + 1] = (T ^ t1) & kFF;
-        s[4 * q + 2] = (T ^ t3) & kFF;
-        s[4 * q + 3] = (T ^ t0) & kFF;
+        const uint32_t T = lin_sum(t0, t1, t2, t3, k63);
+        s[4 * q] = lin_out(T, t2, kFF);
+        s[4 * q + 1] = lin_out(T, t1, kFF);
+        s[4 * q + 2] = lin_out(T, t3, kFF);
+        s[4 * q + 3] = lin_out(T, t0, kFF);
     }
     // (3) ring add (src/hash.rs:77-81), round constants stay pending.  With a_w = byte w (lane 0) and
     // b_w = byte 16+w (lane 1) the sequential in-place recurrence is lane-parallel for words 1..14:
@@ -236,7 +257,10 @@ SMI_HD void from_words(const uint32_t P[8], State &st) {
 #pragma unroll
     for (int w = 0; w < 16; w++) {
         const uint32_t k = (uint32_t)w & 3u;
-        st.s[w] = perm8(P[(w >> 2) + 4], P[w >> 2], 0x0C000C00u | ((4u + k) << 16) | k);
+        if (SMI_CONST_P(P[(w >> 2) + 4]) && SMI_CONST_P(P[w >> 2]))
+            st.s[w] = ((P[w >> 2] >> (8 * k)) & 0xFFu) | (((P[(w >> 2) + 4] >> (8 * k)) & 0xFFu) << 16);
+        else
+            st.s[w] = perm8(P[(w >> 2) + 4], P[w >> 2], 0x0C000C00u | ((4u + k) << 16) | k);
     }
 }
 SMI_HD uint32_t add_bytes(uint32_t a, uint32_t b) {   // four independent sums mod 256
@@ -389,16 +413,16 @@ template <bool PENDING> SMI_HD void mix2_t(State2 &st) {
 #pragma unroll
     for (int w = 0; w < 32; w++) {
         const uint32_t t = pk_mad_u16(s[w], 0x01F601F6u, PENDING ? C.rc502[w] : 0u);
-        r[w] = bfi32(kFE, t, t >> 8);
+        r[w] = sbox_tail(t, kFE);
     }
 #pragma unroll
     for (int q = 0; q < 8; q++) {
         const uint32_t t0 = r[4 * q], t1 = r[4 * q + 1], t2 = r[4 * q + 2], t3 = r[4 * q + 3];
-        const uint32_t T = xor3(xor3(t0, t1, t2), t3, k63);
-        s[4 * q] = (T ^ t2) & kFF;
-        s[4 * q + 1] = (T ^ t1) & kFF;
-        s[4 * q + 2] = (T ^ t3) & kFF;
-        s[4 * q + 3] = (T ^ t0) & kFF;
+        const uint32_t T = lin_sum(t0, t1, t2, t3, k63);
+        s[4 * q] = lin_out(T, t2, kFF);
+        s[4 * q + 1] = lin_out(T, t1, kFF);
+        s[4 * q + 2] = lin_out(T, t3, kFF);
+        s[4 * q + 3] = lin_out(T, t0, kFF);
     }
     // src/hash.rs:77-81 as written, both lanes at once; a lane never exceeds 32*2*255 + 1020 < 2^16
     uint32_t N[32];
@@ -417,7 +441,10 @@ SMI_HD void from_words2(const uint32_t X[8], const uint32_t Y[8], State2 &st) {
 #pragma unroll
     for (int w = 0; w < 32; w++) {
         const uint32_t k = (uint32_t)w & 3u;
-        st.s[w] = perm8(Y[w >> 2], X[w >> 2], 0x0C000C00u | ((4u + k) << 16) | k);
+        if (SMI_CONST_P(X[w >> 2]) && SMI_CONST_P(Y[w >> 2]))   // untouched initial-state words of a leaf: fold
+            st.s[w] = ((X[w >> 2] >> (8 * k)) & 0xFFu) | (((Y[w >> 2] >> (8 * k)) & 0xFFu) << 16);
+        else
+            st.s[w] = perm8(Y[w >> 2], X[w >> 2], 0x0C000C00u | ((4u + k) << 16) | k);
     }
 }
 SMI_HD void to_words2(const State2 &st, uint32_t X[8], uint32_t Y[8]) {
