@@ -167,6 +167,78 @@ extern "C" void emu_node_hash(const uint8_t *pairs, size_t n, uint8_t *out) {
         memcpy(out + 32 * i, d, 32);
     }
 }
+// ---- one hash over a quad of lanes (hash_quad.h): the device code itself, with `word` = four lanes
+// stepped in lockstep and the DPP quad_perm move as a permutation of those four values
+struct Q4 {
+    uint32_t v[4];
+    Q4() : v{0, 0, 0, 0} {}
+    Q4(uint32_t x) : v{x, x, x, x} {}
+    Q4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) : v{a, b, c, d} {}
+};
+#define Q4_BIN(op)                                                 \
+    inline Q4 operator op(const Q4 &a, const Q4 &b) {              \
+        Q4 r;                                                      \
+        for (int i = 0; i < 4; i++) r.v[i] = a.v[i] op b.v[i];     \
+        return r;                                                  \
+    }
+Q4_BIN(+) Q4_BIN(^) Q4_BIN(&) Q4_BIN(|) Q4_BIN(*)
+#undef Q4_BIN
+inline Q4 operator<<(const Q4 &a, int sh) { return Q4(a.v[0] << sh, a.v[1] << sh, a.v[2] << sh, a.v[3] << sh); }
+inline Q4 operator>>(const Q4 &a, int sh) { return Q4(a.v[0] >> sh, a.v[1] >> sh, a.v[2] >> sh, a.v[3] >> sh); }
+namespace hashc {
+#define Q4_MAP3(name)                                                          \
+    inline Q4 name(const Q4 &a, const Q4 &b, const Q4 &c) {                    \
+        Q4 r;                                                                  \
+        for (int i = 0; i < 4; i++) r.v[i] = name(a.v[i], b.v[i], c.v[i]);     \
+        return r;                                                              \
+    }
+Q4_MAP3(pk_mad_u16) Q4_MAP3(bfi32) Q4_MAP3(xor3) Q4_MAP3(add3)
+#undef Q4_MAP3
+inline Q4 dup_hi16(const Q4 &a) { return Q4(dup_hi16(a.v[0]), dup_hi16(a.v[1]), dup_hi16(a.v[2]), dup_hi16(a.v[3])); }
+inline Q4 funnel16(const Q4 &hi, const Q4 &lo) {
+    return Q4(funnel16(hi.v[0], lo.v[0]), funnel16(hi.v[1], lo.v[1]), funnel16(hi.v[2], lo.v[2]), funnel16(hi.v[3], lo.v[3]));
+}
+inline Q4 perm8(const Q4 &hi, const Q4 &lo, uint32_t sel) {
+    return Q4(perm8(hi.v[0], lo.v[0], sel), perm8(hi.v[1], lo.v[1], sel), perm8(hi.v[2], lo.v[2], sel), perm8(hi.v[3], lo.v[3], sel));
+}
+inline void absorb32_words(Q4 P[8], const Q4 M[8]) {   // every lane runs the whole absorb, as on the device
+    for (int i = 0; i < 4; i++) {
+        uint32_t p[8], m[8];
+        for (int j = 0; j < 8; j++) { p[j] = P[j].v[i]; m[j] = M[j].v[i]; }
+        absorb32_words(p, m);
+        for (int j = 0; j < 8; j++) P[j].v[i] = p[j];
+    }
+}
+}  // namespace hashc
+#define SMI_QUAD_EMU
+namespace hashq {
+#define SMI_QD inline
+typedef Q4 word;
+template <int P0, int P1, int P2, int P3> inline Q4 quad(const Q4 &x) { return Q4(x.v[P0], x.v[P1], x.v[P2], x.v[P3]); }
+inline Q4 lane_in_quad(uint32_t) { return Q4(0, 1, 2, 3); }
+inline Q4 mask_ge(const Q4 &q, uint32_t k) { return Q4(q.v[0] >= k ? ~0u : 0u, q.v[1] >= k ? ~0u : 0u, q.v[2] >= k ? ~0u : 0u, q.v[3] >= k ? ~0u : 0u); }
+inline Q4 mask_eq(const Q4 &q, uint32_t k) { return Q4(q.v[0] == k ? ~0u : 0u, q.v[1] == k ? ~0u : 0u, q.v[2] == k ? ~0u : 0u, q.v[3] == k ? ~0u : 0u); }
+inline Q4 sel4(const Q4 &q, const Q4 &a, const Q4 &b, const Q4 &c, const Q4 &d) {
+    Q4 r;
+    for (int i = 0; i < 4; i++) r.v[i] = q.v[i] == 0 ? a.v[i] : q.v[i] == 1 ? b.v[i] : q.v[i] == 2 ? c.v[i] : d.v[i];
+    return r;
+}
+}  // namespace hashq
+#include "hash_quad.h"
+extern "C" void emu_node_hash_quad(const uint8_t *pairs, size_t n, uint8_t *out) {
+    const hashq::Lane L = hashq::make_lane(0);
+    for (size_t i = 0; i < n; i++) {
+        uint32_t l[8], r[8], d[8];
+        memcpy(l, pairs + 64 * i, 32);
+        memcpy(r, pairs + 64 * i + 32, 32);
+        Q4 ql[8], qr[8], lo, hi;
+        for (int j = 0; j < 8; j++) { ql[j] = Q4(l[j]); qr[j] = Q4(r[j]); }
+        hashq::node_hash(ql, qr, L, lo, hi);
+        for (int q = 0; q < 4; q++) { d[q] = lo.v[q]; d[4 + q] = hi.v[q]; }
+        memcpy(out + 32 * i, d, 32);
+    }
+}
+
 // rows of W residues, row-major in `v`: pairs through row_hash2 when W <= 4, the rest through row_hash
 extern "C" void emu_row_hash(const uint32_t *v, size_t n_rows, int W, uint8_t *out) {
     size_t i = 0;

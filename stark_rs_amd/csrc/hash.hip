@@ -13,6 +13,7 @@
 // <= 2048 digests.  Roofline: integer VALU issue (~0.9k instructions per leaf hash, ~1.2k per node
 // hash), not HBM -- DESIGN.md section 3.
 #include "hash_core.h"
+#include "hash_quad.h"
 #include "internal.h"
 
 #define SMI_HASH_THREADS 256
@@ -117,6 +118,9 @@ __global__ __launch_bounds__(SMI_HASH_THREADS) void merkle_sub_kernel(const uint
 #ifndef SMI_TOP_UNROLL
 #define SMI_TOP_UNROLL 8   // closing mixes of a node hash scheduled together (see hashc::node_hash)
 #endif
+#ifndef SMI_TOP_QUAD
+#define SMI_TOP_QUAD 1     // levels with at most SMI_TOP_THREADS / 4 nodes hash over quads of lanes
+#endif
 #define SMI_TOP_MAX 2048
 #define SMI_TOP_THREADS (SMI_TOP_MAX / 2)
 template <bool FROM_ELEMS>
@@ -150,9 +154,35 @@ __global__ __launch_bounds__(SMI_TOP_THREADS) void merkle_top_kernel(const uint3
     }
     __syncthreads();
     uint32_t lvl = lvl_in;
+    const hashq::Lane lane = hashq::make_lane(tid);
     for (uint32_t cnt = chunk; cnt > 1; cnt >>= 1) {   // cnt, lvl are workgroup-uniform
         const uint32_t half = cnt >> 1;
         lvl++;
+        if (SMI_TOP_QUAD && 4 * half <= SMI_TOP_THREADS) {
+            // few nodes: a level is one node-hash latency, so each hash is spread over a quad of lanes
+            // (hash_quad.h); lane q of the quad ends up with digest words q and q+4
+            const uint32_t node = tid >> 2;
+            uint32_t lo = 0, hi = 0;
+            if (node < half) {
+                uint32_t l[8], r[8];
+#pragma unroll
+                for (int w = 0; w < 8; w++) {
+                    l[w] = buf[w * SMI_TOP_MAX + 2 * node];
+                    r[w] = buf[w * SMI_TOP_MAX + 2 * node + 1];
+                }
+                hashq::node_hash(l, r, lane, lo, hi);
+                uint32_t *dst = (uint32_t *)(nodes + 2 * (level_offset(n, lvl) + (first >> (lvl - lvl_in)) + node));
+                dst[lane.q] = lo;
+                dst[4 + lane.q] = hi;
+            }
+            __syncthreads();   // every pair of this level has been read
+            if (node < half) {
+                buf[lane.q * SMI_TOP_MAX + node] = lo;
+                buf[(4 + lane.q) * SMI_TOP_MAX + node] = hi;
+            }
+            __syncthreads();
+            continue;
+        }
         if (tid < half) {
             uint32_t l[8], r[8];
 #pragma unroll

@@ -85,6 +85,25 @@ def test_emulated_hash_core(emu, oracle):
         assert bytes(ob) == o.hash_from_bytes(m)
 
 
+def test_emulated_node_hash_over_a_quad_of_lanes(emu, oracle):
+    """hash_quad.h (the upper Merkle levels of merkle_top_kernel: one hash spread over four lanes, the
+    ring add as a local prefix plus a 4-lane scan over quad_perm moves) stepped in lockstep on the CPU:
+    Hash::combine of random, all-zero, all-ones and repeated-byte children."""
+    o = oracle
+    rng = np.random.default_rng(9)
+    pairs = rng.integers(0, 256, (300, 64), dtype=np.uint8)
+    pairs[0] = 0
+    pairs[1] = 255
+    pairs[2, :32] = 0
+    pairs[3, 32:] = 255
+    for k in range(4, 20):
+        pairs[k] = (k * 37) & 255
+    out = np.zeros((len(pairs), 32), dtype=np.uint8)
+    emu.emu_node_hash_quad(pairs.ctypes.data_as(C.c_void_p), C.c_size_t(len(pairs)), out.ctypes.data_as(C.c_void_p))
+    for i in range(len(pairs)):
+        assert bytes(out[i]) == o.hash_combine(bytes(pairs[i, :32]), bytes(pairs[i, 32:])), i
+
+
 @pytest.mark.parametrize("L,plan", [
     (18, "9.3,9.3"), (18, "9.5,9.4"), (18, "10.4,8.4"), (18, "6.6,6.6,6.6"), (19, "7.6,6.6,6.6"), (20, "10.2,10.2"),
     (20, "10.4,10.3"), (20, "7.5,7.5,6.6"), (20, "8.6,6.6,6.6"), (21, "8.5,7.6,6.6"), (21, "9.4,6.6,6.6"),

@@ -345,8 +345,11 @@ def test_combine_and_bytes(eng, oracle):
     assert eng.hash_bytes(b"hello").hex() == "663afaa74185a1693451aa7fd22ac722ff8f89aabc0471f28dc7c2b7354cae8e"
 
 
-@pytest.mark.parametrize("logn", [0, 1, 2, 3, 4, 7, 10, 13, 16])
+@pytest.mark.parametrize("logn", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 16, 18])
 def test_merkle_tree_all_levels(eng, oracle, logn):
+    """Every level of MerkleTree::new against the oracle.  The sizes cover each way the kernels split a
+    tree: thread-local subtrees, chunk workgroups, and inside a chunk the levels hashed one node per
+    lane against those hashed over quads of lanes (hash_quad.h: levels of at most 256 nodes)."""
     o = oracle
     n = 1 << logn
     cw = _vals(o, 77 + logn, n)
