@@ -153,7 +153,7 @@ __global__ __launch_bounds__(SMI_TOP_THREADS) void merkle_top_kernel(const uint3
         for (int w = 0; w < 8; w++) buf[w * SMI_TOP_MAX + i] = d[w];
     }
     __syncthreads();
-    uint32_t lvl = lvl_in;
+    uint32_t lvl = lvl_in, base = 0;
     const hashq::Lane lane = hashq::make_lane(tid);
     for (uint32_t cnt = chunk; cnt > 1; cnt >>= 1) {   // cnt, lvl are workgroup-uniform
         const uint32_t half = cnt >> 1;
@@ -161,25 +161,24 @@ __global__ __launch_bounds__(SMI_TOP_THREADS) void merkle_top_kernel(const uint3
         if (SMI_TOP_QUAD && 4 * half <= SMI_TOP_THREADS) {
             // few nodes: a level is one node-hash latency, so each hash is spread over a quad of lanes
             // (hash_quad.h); lane q of the quad ends up with digest words q and q+4
+            // These levels hold at most 512 digests, so they alternate between slots [0, 512) and
+            // [1024, 1536) of each word row: one barrier per level instead of two.
             const uint32_t node = tid >> 2;
-            uint32_t lo = 0, hi = 0;
             if (node < half) {
-                uint32_t l[8], r[8];
+                uint32_t l[8], r[8], lo, hi;
 #pragma unroll
                 for (int w = 0; w < 8; w++) {
-                    l[w] = buf[w * SMI_TOP_MAX + 2 * node];
-                    r[w] = buf[w * SMI_TOP_MAX + 2 * node + 1];
+                    l[w] = buf[w * SMI_TOP_MAX + base + 2 * node];
+                    r[w] = buf[w * SMI_TOP_MAX + base + 2 * node + 1];
                 }
                 hashq::node_hash(l, r, lane, lo, hi);
                 uint32_t *dst = (uint32_t *)(nodes + 2 * (level_offset(n, lvl) + (first >> (lvl - lvl_in)) + node));
                 dst[lane.q] = lo;
                 dst[4 + lane.q] = hi;
+                buf[lane.q * SMI_TOP_MAX + (base ^ (SMI_TOP_MAX / 2)) + node] = lo;
+                buf[(4 + lane.q) * SMI_TOP_MAX + (base ^ (SMI_TOP_MAX / 2)) + node] = hi;
             }
-            __syncthreads();   // every pair of this level has been read
-            if (node < half) {
-                buf[lane.q * SMI_TOP_MAX + node] = lo;
-                buf[(4 + lane.q) * SMI_TOP_MAX + node] = hi;
-            }
+            base ^= SMI_TOP_MAX / 2;
             __syncthreads();
             continue;
         }
