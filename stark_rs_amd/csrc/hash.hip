@@ -366,9 +366,19 @@ int launch_merkle_batch(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t
     while (lvl < depth || from_elems) {
         // Once what is left fits the chip as one wave of chunk workgroups, the per-level latency of
         // the chunk kernel beats two-level launches: up to SMI_TOP_MAX digests (11 levels) per launch.
-        const size_t chunk = count < SMI_TOP_MAX ? count : SMI_TOP_MAX;
+        // Chunks are as small as one workgroup per CU allows (not below 64): the widest levels of a chunk
+        // are throughput on a single CU, so 256 chunks of 256 digests and then their 256 roots finish a
+        // 2^16-leaf tree in 42 us where 32 chunks of 2048 took 65.  Up to 512 digests stay one chunk.
+        // (Both bounds are tuning knobs; tools/sweep_merkle_chunks.sh: flat within 3 % from 8 to 64.)
+        static const size_t SINGLE_MAX = [] { const char *e = getenv("SMI_MERKLE_SINGLE"); return (size_t)(e ? atoi(e) : 512); }();
+        static const size_t MIN_CHUNK = [] { const char *e = getenv("SMI_MERKLE_MINCHUNK"); return (size_t)(e ? atoi(e) : 64); }();
+        size_t chunk = count;
+        if (count > SINGLE_MAX) {
+            chunk = MIN_CHUNK;
+            while (chunk < SMI_TOP_MAX && (count / chunk) * n_trees > TOP_BLOCKS) chunk <<= 1;
+        }
         const size_t n_chunks = count / chunk;
-        if (n_chunks * n_trees <= TOP_BLOCKS) {
+        if (chunk <= SMI_TOP_MAX && n_chunks * n_trees <= TOP_BLOCKS) {
             const double hashed = (from_elems ? 2.0 * (double)count : (double)count) - (double)n_chunks;
             ProfScope ps(ctx, "merkle_top_kernel", ((from_elems ? 4.0 * (row_cols ? row_cols : 1) : 32.0) * (double)count + 32.0 * hashed) * n_trees);
             const dim3 grid((uint32_t)n_chunks, n_trees);
