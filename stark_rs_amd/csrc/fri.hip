@@ -82,7 +82,7 @@ __global__ void fs_challenge_kernel(const FsState *fs, uint64_t *alpha_out) {
 // sequential loop (distinct modulo reduced_size).  `number` <= reduced_size is checked on the host.
 __global__ __launch_bounds__(64) void sample_indices_kernel(const uint64_t *challenge, uint64_t size, uint64_t reduced_size,
                                                             uint32_t number, uint64_t *indices, uint64_t *reduced) {
-    __shared__ uint64_t cand[64];
+    __shared__ uint64_t cand[64], cand_r[64];
     __shared__ uint64_t s_red[256];   // accepted reduced indices, mirrored in LDS: the acceptance loop is O(number^2) look-ups
     __shared__ uint32_t s_cnt;
     const uint32_t lane = threadIdx.x;
@@ -100,6 +100,7 @@ __global__ __launch_bounds__(64) void sample_indices_kernel(const uint64_t *chal
     hashc::init(base);
     hashc::absorb_chunk32(base, seed);
     if (lane == 0) s_cnt = 0;
+    uint64_t held[4] = {0, 0, 0, 0};
     __syncthreads();
     for (uint32_t batch = 0; batch < (1u << 20); batch++) {   // bounded: ends as soon as `number` are accepted
         const uint32_t counter = batch * 64u + lane;
@@ -115,12 +116,38 @@ __global__ __launch_bounds__(64) void sample_indices_kernel(const uint64_t *chal
         uint64_t acc = 0;
 #pragma unroll
         for (int i = 24; i < 32; i++) acc = (acc << 8) | ((d[i >> 2] >> (8 * (i & 3))) & 0xFFu);
-        cand[lane] = acc % size;
+        // both moduli are powers of two on every FRI path (lengths of codewords): a mask instead of
+        // a 64-bit division; every lane reduces its own candidate, lane 0 only compares
+        const uint64_t index_l = (size & (size - 1)) ? acc % size : acc & (size - 1);
+        cand[lane] = index_l;
+        cand_r[lane] = (reduced_size & (reduced_size - 1)) ? index_l % reduced_size : index_l & (reduced_size - 1);
         __syncthreads();
-        if (lane == 0) {
+        if (number <= 256) {
+            // acceptance in candidate order, the look-up spread over the wave: lane l keeps the accepted
+            // reduced indices l, l+64, l+128, l+192 in registers and a ballot answers "seen before?"
+            uint32_t cnt = s_cnt;   // wave-uniform
+            for (uint32_t k = 0; k < 64 && cnt < number; k++) {
+                const uint64_t index = cand[k], ri = cand_r[k];
+                bool hit = false;
+#pragma unroll
+                for (uint32_t m = 0; m < 4; m++) hit |= lane + 64u * m < cnt && held[m] == ri;
+                if (__ballot(hit) == 0) {
+#pragma unroll
+                    for (uint32_t m = 0; m < 4; m++)
+                        if ((cnt >> 6) == m && (cnt & 63u) == lane) held[m] = ri;
+                    if (lane == 0) {
+                        indices[cnt] = index;
+                        reduced[cnt] = ri;
+                    }
+                    cnt++;
+                }
+            }
+            __syncthreads();
+            if (lane == 0) s_cnt = cnt;
+        } else if (lane == 0) {
             uint32_t cnt = s_cnt;
             for (uint32_t k = 0; k < 64 && cnt < number; k++) {
-                const uint64_t index = cand[k], ri = index % reduced_size;
+                const uint64_t index = cand[k], ri = cand_r[k];
                 bool seen = false;
                 for (uint32_t j = 0; j < cnt; j++) seen |= (j < 256 ? s_red[j] : reduced[j]) == ri;
                 if (!seen) {
