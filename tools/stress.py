@@ -21,6 +21,7 @@ def main():
     engs = {s.P_REF: s.Engine(s.P_REF, s.G_REF, 0), s.P2: s.Engine(s.P2, s.G2, 0)}
     gens = {s.P_REF: s.G_REF, s.P2: s.G2}
     t0, n_cases = time.time(), 0
+    last_note = t0
     while time.time() - t0 < budget:
         p = int(rng.choice([s.P_REF, s.P2]))
         e, g = engs[p], gens[p]
@@ -102,6 +103,9 @@ def main():
         else:
             continue
         n_cases += 1
+        if time.time() - last_note > 30:     # a line every half minute: long runs must not look hung
+            last_note = time.time()
+            print(f"stress: {n_cases} cases so far ({last_note - t0:.0f} s)", flush=True)
     print(f"stress: {n_cases} random cases in {time.time() - t0:.0f} s, all equal to the oracle", flush=True)
 
 
