@@ -11,6 +11,9 @@
 #include "internal.h"
 
 int launch_merkle(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_nodes);
+// the same, with the Fiat-Shamir round of the root run by the launch that produces it (*done says whether it was)
+int launch_merkle_fs(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_nodes, uint32_t *fs_words, uint8_t *proof_slot,
+                     uint64_t *alpha_out, bool *done);
 
 // ------------------------------------------------------------------------- fold
 // out[i] = 2^-1 * ((1 + a/x_i) c[i] + (1 - a/x_i) c[i+h])            (src/fri.rs:70-88)
@@ -47,22 +50,9 @@ __global__ void fs_init_kernel(FsState *fs) {
 // buffer, and if alpha_out != nullptr draw the challenge.
 __global__ void fs_round_kernel(FsState *fs, const uint32_t *root, uint8_t *proof_slot, uint64_t *alpha_out) {
     if (threadIdx.x || blockIdx.x) return;
-    hashc::State st;
-    for (int i = 0; i < 16; i++) st.s[i] = fs->s[i];
     uint32_t m[8];
     for (int i = 0; i < 8; i++) m[i] = root[i];
-    hashc::absorb_chunk32(st, m);
-    for (int i = 0; i < 16; i++) fs->s[i] = st.s[i];
-    if (proof_slot) {
-        proof_slot[0] = 0;
-        for (int i = 0; i < 32; i++) proof_slot[1 + i] = (uint8_t)(m[i >> 2] >> (8 * (i & 3)));
-    }
-    if (alpha_out) {
-        for (int k = 0; k < 8; k++) hashc::mix(st);
-        uint32_t d[8];
-        hashc::to_words(st, d);
-        *alpha_out = (uint64_t)d[0] | ((uint64_t)d[1] << 32);
-    }
+    hashc::fs_absorb_root(fs->s, m, proof_slot, alpha_out);
 }
 
 // challenge without absorbing (src/fri.rs:272: the index-sampling seed)
@@ -412,11 +402,16 @@ int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, si
         run->trees.push_back(nodes);
         run->codewords.push_back(const_cast<uint32_t *>(cur));
         run->lens.push_back(cur_len);
-        if ((rc = launch_merkle(ctx, cur, cur_len, nodes)) != SMI_OK) return bail(rc);
         const uint32_t *root = (const uint32_t *)(nodes + (2 * cur_len - 2) * 32);
         const bool last = r == R - 1;
-        // push root, absorb, challenge (src/fri.rs:129-138)
-        fs_round_kernel<<<1, 64, 0, ctx->stream>>>(d_fs, root, run->d_proof + off_roots + 33 * r, last ? nullptr : d_alphas + r);
+        // push root, absorb, challenge (src/fri.rs:129-138): done by the workgroup that finishes the tree
+        // when that is the chunk kernel (one launch fewer per round), by a kernel of its own otherwise
+        bool fs_done = false;
+        if ((rc = launch_merkle_fs(ctx, cur, cur_len, nodes, d_fs->s, run->d_proof + off_roots + 33 * r, last ? nullptr : d_alphas + r,
+                                   &fs_done)) != SMI_OK)
+            return bail(rc);
+        if (!fs_done)
+            fs_round_kernel<<<1, 64, 0, ctx->stream>>>(d_fs, root, run->d_proof + off_roots + 33 * r, last ? nullptr : d_alphas + r);
         if (last) break;
         uint32_t *next = (uint32_t *)run_alloc(run, (cur_len / 2) * 4);
         if (!next) return bail(smi_fail(ctx, SMI_ERR_OOM, "alloc codeword"));

@@ -123,10 +123,18 @@ __global__ __launch_bounds__(SMI_HASH_THREADS) void merkle_sub_kernel(const uint
 #endif
 #define SMI_TOP_MAX 2048
 #define SMI_TOP_THREADS (SMI_TOP_MAX / 2)
+// Optional epilogue of the launch that produces a tree's root: the Fiat-Shamir round of Fri::commit
+// (hashc::fs_absorb_root) by lane 0 of the workgroup holding the root -- one launch fewer per FRI round.
+struct TopHook {
+    uint32_t *fs_words;    // nullptr: no epilogue
+    uint8_t *proof_slot;
+    uint64_t *alpha_out;
+};
 template <bool FROM_ELEMS>
 __global__ __launch_bounds__(SMI_TOP_THREADS) void merkle_top_kernel(const uint32_t *__restrict__ elems, uint4 *nodes, size_t n,
                                                                       uint32_t lvl_in, uint32_t chunk, size_t elem_stride,
-                                                                      size_t node_stride, uint32_t row_cols, size_t row_stride) {
+                                                                      size_t node_stride, uint32_t row_cols, size_t row_stride,
+                                                                      TopHook hook) {
     __shared__ uint32_t buf[8 * SMI_TOP_MAX];
     elems += (size_t)blockIdx.y * elem_stride;
     nodes += (size_t)blockIdx.y * node_stride;
@@ -200,6 +208,12 @@ __global__ __launch_bounds__(SMI_TOP_THREADS) void merkle_top_kernel(const uint3
             for (int w = 0; w < 8; w++) buf[w * SMI_TOP_MAX + tid] = d[w];
         }
         __syncthreads();
+    }
+    if (hook.fs_words && tid == 0 && gridDim.x == 1 && blockIdx.y == 0) {   // the root sits in slot `base` of every word row
+        uint32_t m[8];
+#pragma unroll
+        for (int w = 0; w < 8; w++) m[w] = buf[w * SMI_TOP_MAX + base];
+        hashc::fs_absorb_root(hook.fs_words, m, hook.proof_slot, hook.alpha_out);
     }
 }
 
@@ -327,8 +341,18 @@ static uint32_t log2_floor(size_t n) {
 // hashed from the codeword first (fused with the bottom levels).  n must be a power of two.
 int launch_merkle_batch(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_nodes, uint32_t n_trees, size_t elem_stride,
                         size_t node_stride_bytes, uint32_t row_cols = 0, size_t row_stride = 0);
+static int launch_merkle_impl(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_nodes, uint32_t n_trees, size_t elem_stride,
+                              size_t node_stride_bytes, uint32_t row_cols, size_t row_stride, const TopHook *hook, bool *hook_done);
 int launch_merkle(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_nodes) {
     return launch_merkle_batch(ctx, d_elems, n, d_nodes, 1, 0, 0);
+}
+// one tree, with the Fiat-Shamir round of its root run by the launch that produces it when that is the
+// chunk kernel (*done tells the caller whether it was)
+int launch_merkle_fs(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_nodes, uint32_t *fs_words, uint8_t *proof_slot,
+                     uint64_t *alpha_out, bool *done) {
+    const TopHook hook{fs_words, proof_slot, alpha_out};
+    *done = false;
+    return launch_merkle_impl(ctx, d_elems, n, d_nodes, 1, 0, 0, 0, 0, &hook, done);
 }
 // one tree whose leaf i hashes row i of n_cols columns (column c at d_cols + c*col_stride)
 int launch_merkle_rows(smi_ctx *ctx, const uint32_t *d_cols, uint32_t n_cols, size_t col_stride, size_t n, uint8_t *d_nodes) {
@@ -342,6 +366,10 @@ int launch_merkle_rows(smi_ctx *ctx, const uint32_t *d_cols, uint32_t n_cols, si
 // d_nodes + y*node_stride_bytes.  The small upper levels of all trees share their launch latency.
 int launch_merkle_batch(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_nodes, uint32_t n_trees, size_t elem_stride,
                         size_t node_stride_bytes, uint32_t row_cols, size_t row_stride) {
+    return launch_merkle_impl(ctx, d_elems, n, d_nodes, n_trees, elem_stride, node_stride_bytes, row_cols, row_stride, nullptr, nullptr);
+}
+static int launch_merkle_impl(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_nodes, uint32_t n_trees, size_t elem_stride,
+                              size_t node_stride_bytes, uint32_t row_cols, size_t row_stride, const TopHook *hook, bool *hook_done) {
     if (!n_trees) return SMI_OK;
     const size_t node_stride = node_stride_bytes / 16;
     const uint32_t depth = log2_floor(n);
@@ -382,10 +410,15 @@ int launch_merkle_batch(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t
             const double hashed = (from_elems ? 2.0 * (double)count : (double)count) - (double)n_chunks;
             ProfScope ps(ctx, "merkle_top_kernel", ((from_elems ? 4.0 * (row_cols ? row_cols : 1) : 32.0) * (double)count + 32.0 * hashed) * n_trees);
             const dim3 grid((uint32_t)n_chunks, n_trees);
+            TopHook h{nullptr, nullptr, nullptr};
+            if (hook && n_chunks == 1 && n_trees == 1) {   // this launch ends with the root
+                h = *hook;
+                *hook_done = true;
+            }
             if (from_elems)
-                merkle_top_kernel<true><<<grid, SMI_TOP_THREADS, 0, ctx->stream>>>(d_elems, nodes, n, 0, (uint32_t)chunk, elem_stride, node_stride, row_cols, row_stride);
+                merkle_top_kernel<true><<<grid, SMI_TOP_THREADS, 0, ctx->stream>>>(d_elems, nodes, n, 0, (uint32_t)chunk, elem_stride, node_stride, row_cols, row_stride, h);
             else
-                merkle_top_kernel<false><<<grid, SMI_TOP_THREADS, 0, ctx->stream>>>(nullptr, nodes, n, lvl, (uint32_t)chunk, 0, node_stride, 0, 0);
+                merkle_top_kernel<false><<<grid, SMI_TOP_THREADS, 0, ctx->stream>>>(nullptr, nodes, n, lvl, (uint32_t)chunk, 0, node_stride, 0, 0, h);
             HIP_TRY(ctx, hipGetLastError());
             from_elems = false;
             uint32_t up = 0;

@@ -329,6 +329,27 @@ SMI_HD void absorb_chunk32(State &st, const uint32_t m[8]) {
     mix(st);
 }
 
+// One Fiat-Shamir round of Fri::commit on a transcript kept as the sponge state after its whole chunks
+// (only 32-byte roots are ever absorbed, src/fri.rs:131): absorb the root, append it to the proof (tag 0
+// + 32 bytes, src/stream.rs:39-42) and, unless this is the last round, draw the challenge
+// (src/fiat_shamir.rs:19-25: the first 8 digest bytes, unreduced).  Single lane.
+SMI_HD void fs_absorb_root(uint32_t *fs_words, const uint32_t m[8], uint8_t *proof_slot, uint64_t *alpha_out) {
+    State st;
+    for (int i = 0; i < 16; i++) st.s[i] = fs_words[i];
+    absorb_chunk32(st, m);
+    for (int i = 0; i < 16; i++) fs_words[i] = st.s[i];
+    if (proof_slot) {
+        proof_slot[0] = 0;
+        for (int i = 0; i < 32; i++) proof_slot[1 + i] = (uint8_t)(m[i >> 2] >> (8 * (i & 3)));
+    }
+    if (alpha_out) {
+        for (int k = 0; k < 8; k++) mix(st);
+        uint32_t d[8];
+        to_words(st, d);
+        *alpha_out = (uint64_t)d[0] | ((uint64_t)d[1] << 32);
+    }
+}
+
 // Hash::from_field_elements(&[v as u64]) (src/hash.rs:32-35 as used by src/fri.rs:118-121):
 // 8 message bytes (LE u64 of a u32 residue: the upper four are zero), 1 + 8 mixes.
 // the 8-byte chunk of a leaf in natural layout: it touches bytes 0..14 -- v_0..v_7 as in
