@@ -73,7 +73,7 @@ def cpu_baseline():
     t4 = time.perf_counter()
     # ... and on all host cores: independent columns, one per thread (the C oracle runs outside the GIL)
     from concurrent.futures import ThreadPoolExecutor
-    n_thr = max(1, min(16, os.cpu_count() or 1))
+    n_thr = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
     col_job = lambda c: o.fast_coset_ntt(o.fast_intt(splitmix64(100 + c, 1 << 20) % np.uint64(p), w20, 1), 1 << 23, w23, 3)[0]
     t8 = time.perf_counter()
     with ThreadPoolExecutor(n_thr) as ex:
@@ -90,7 +90,16 @@ def cpu_baseline():
     wm = o.ff_prim_nth_root(m)
     o.fri_fold_codeword(o.fri_cfg(wm, 3, m, 8, 32), cw, 0x0123456789ABCDEF, 3, wm)
     t7 = time.perf_counter()
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {
+        "cpu_model": model, "host_cores": os.cpu_count(), "threads_used": 1,
         "merkle_node_hashes_per_s": (m - 1) / (t6 - t5), "fold_elements_per_s": (m // 2) / (t7 - t6),
         "commit_sample": f"oracle MerkleTree::new over 2^18 digests ({t6 - t5:.2f}s), Fri::fold_codeword of 2^18 elements ({t7 - t6:.2f}s), 1 thread",
         "value": n_cols * (n + N) / (t_int + t_ev), "unit": "field-elements/s", "cores": 1, "kind": "port",
@@ -109,6 +118,29 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-extras", action="store_true", help="skip prove / 2^20 / four-step / cpu legs")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` (N > 1) outside a launcher: start one rank per GPU ourselves, as a
+    # child process, BEFORE anything in this process touches the GPU (no exec after HIP init), and
+    # relay the ranks' output (rank 0 prints the JSON line).  Under torch.distributed.run the
+    # launcher's WORLD_SIZE must agree with --gpus, so a one-GPU number can never be recorded as an
+    # N-GPU result.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
+               "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+        if args.no_extras:
+            cmd.append("--no-extras")
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(cmd, env=env))
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env}: refusing to mislabel the run", file=sys.stderr)
+        sys.exit(2)
 
     import torch
     import torch.distributed as dist
@@ -156,7 +188,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    eng.profile(True)
+    # headline: exactly K un-instrumented steps between barrier + synchronize on both sides
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -165,12 +197,19 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    kernels = eng.profile_read()
-    eng.profile(False)
     if distributed:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    # roofline: a second set of steps with a HIP-event bracket around every launch (on the
+    # engine's stream), outside the headline timing
+    prof_steps = max(5, min(args.steps, 20))
+    eng.profile(True)
+    for _ in range(prof_steps):
+        step()
+    torch.cuda.synchronize()
+    kernels = eng.profile_read()
+    eng.profile(False)
 
     points_per_step = N_COLS * (n + N)                      # transform sizes summed over the batch
     value = world * points_per_step * args.steps / elapsed
@@ -180,13 +219,21 @@ def main():
     avg_ms = dom["total_ms"] / dom["launches"]
     bytes_per_launch = dom["alg_bytes"] / dom["launches"]
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-    traffic = None
+    # HBM traffic per launch from the PMC passes of tools/profile.sh (rocprofv3 --pmc FETCH_SIZE /
+    # WRITE_SIZE in separate runs, gfx950 correction applied there): a measured file committed under
+    # profiles/, not something this run can collect itself; null when the file has no entry for
+    # the dominant kernel of this run.
+    traffic = step_traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):
         try:
-            traffic = json.load(open(pmc_path)).get(dom_name, {}).get("hbm_bytes_per_launch")
+            pmc = json.load(open(pmc_path))
+            traffic = pmc.get(dom_name, {}).get("hbm_bytes_per_launch")
+            per = [pmc.get(k, {}).get("hbm_bytes_per_launch") for k in kernels]
+            if all(x is not None for x in per):     # every launch of a step: launches per step x bytes per launch
+                step_traffic = sum(x * v["launches"] / prof_steps for x, v in zip(per, kernels.values()))
         except Exception:
-            traffic = None
+            traffic = step_traffic = None
     # What HBM delivers for each pass's own access pattern: the copy-only twin of every pass kernel
     # (same tiles, loads and store addresses, no arithmetic), timed the same way.
     eng.copy_probe(True)
@@ -196,14 +243,21 @@ def main():
     probes = eng.profile_read()
     eng.profile(False)
     eng.copy_probe(False)
-    probe_ms = {k.replace("ntt_copy_probe", "ntt_pass_kernel"): v["total_ms"] / v["launches"] for k, v in probes.items()}
-    ntt_ms = sum(k["total_ms"] for k in kernels.values()) / args.steps
+    def twin(k):      # name of the kernel a copy-only twin stands for
+        if k.startswith("lde_copy_probe_a"):
+            return k.replace("lde_copy_probe_a", "lde_a_kernel")
+        return "lde_b_kernel" if k == "lde_copy_probe_b" else k.replace("ntt_copy_probe", "ntt_pass_kernel")
+    probe_ms = {twin(k): v["total_ms"] / v["launches"] for k, v in probes.items()}
+    ntt_ms = sum(k["total_ms"] for k in kernels.values()) / prof_steps
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc, earlier run of the same command)",
                 "avg_launch_ms": avg_ms, "alg_bytes_per_launch": bytes_per_launch,
                 # whole-LDE view: SURVEY 8(d) (12+4B)*n*4 cols algorithmic bytes over the step's kernel time
                 "step_alg_bytes": (12 + 4 * (1 << LOG_BLOWUP)) * n * N_COLS,
                 "step_achieved": (12 + 4 * (1 << LOG_BLOWUP)) * n * N_COLS / (ntt_ms * 1e-3) / 1e9,
+                # ... and against the headline's own clock: algorithmic bytes of a step / ms_per_step / peak
+                "step_frac": (12 + 4 * (1 << LOG_BLOWUP)) * n * N_COLS / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                "step_traffic": step_traffic,
                 # the same launch as a pure copy (no arithmetic): the ceiling of this access pattern
                 "pattern_copy_GBps": (bytes_per_launch / (probe_ms[dom_name] * 1e-3) / 1e9) if dom_name in probe_ms else None,
                 "frac_of_pattern_copy": (probe_ms[dom_name] / avg_ms) if dom_name in probe_ms else None,
@@ -221,14 +275,30 @@ def main():
     }
 
     # The headline line must survive anything the extra legs do: a watchdog thread prints what has
-    # been measured so far and hard-exits if an extra (e.g. a collective on a flaky peer) hangs.
+    # been measured so far and exits NON-ZERO if an extra (e.g. a collective on a flaky peer) hangs;
+    # `stage` names the leg that was in flight.
     import threading
+    lock = threading.Lock()
+    stage = {"name": "start"}
+
+    class Locked(dict):              # the main thread's writes and the watchdog's snapshot never interleave
+        def __setitem__(self, k, v):
+            with lock:
+                dict.__setitem__(self, k, v)
+    result = Locked(result)
+
+    def enter(name):
+        with lock:
+            stage["name"] = name
 
     def _bail():
-        result["extras_timeout"] = True
+        with lock:
+            snap = dict(result)
+            snap["extras_timeout"] = True
+            snap["extras_timeout_stage"] = stage["name"]
         if rank == 0:
-            print(json.dumps(result), flush=True)
-        os._exit(0)
+            print(json.dumps(snap, default=str), flush=True)
+        os._exit(3)
 
     watchdog = threading.Timer(420.0, _bail)
     watchdog.daemon = True
@@ -236,6 +306,7 @@ def main():
 
     if not args.no_extras:
         # ---- end-to-end prove of the same trace (build-defined composition)
+        enter("prove")
         try:
             for _ in range(2):   # warm-up: the first call sizes the device arena, the second allocates it
                 eng.dev_stark_prove(trace.data_ptr(), N_COLS, LOG_ROWS, LOG_BLOWUP, N_TESTS)
@@ -256,6 +327,7 @@ def main():
             result["prove_error"] = str(e)
         # build-defined variant: one tree over the rows of the extended trace instead
         # of one per column -- four columns are one 32-byte chunk, so the commit costs a quarter
+        enter("prove_row_leaves")
         try:
             eng.dev_stark_prove(trace.data_ptr(), N_COLS, LOG_ROWS, LOG_BLOWUP, N_TESTS, row_leaves=True)
             torch.cuda.synchronize()
@@ -267,6 +339,7 @@ def main():
             result["prove_row_leaves_error"] = str(e)
 
         # ---- BASELINE configs[1]: 2^20-point forward + inverse on the reference prime
+        enter("ntt_2p20 / cfg3")
         if rank == 0:
             e1 = s.Engine(s.P_REF, s.G_REF, local_rank)
             x = torch.from_numpy((splitmix64(2, 1 << 20) % np.uint64(s.P_REF)).astype(np.uint32).view(np.int32)).to(dev)
@@ -299,6 +372,7 @@ def main():
             e1.close()
 
         # ---- BASELINE configs[3]: 2^26-point four-step NTT sharded over the N GPUs
+        enter("four_step_2p26")
         if distributed:
           try:
             lr, lc = 13, 13
@@ -324,6 +398,7 @@ def main():
 
         # ---- one 2^25-point codeword sharded over the N GPUs: Fri::commit with per-rank Merkle
         # subtrees, all-gathered sub-roots and the pairwise fold exchange
+        enter("sharded fri / prove")
         if distributed:
           try:
             from stark_rs_amd.sharded import HipShardBackend, ShardedFriCommit
@@ -387,6 +462,7 @@ def main():
             import traceback
             result["sharded_fri_error"] = f"{type(e).__name__}: {e} | {traceback.format_exc(limit=3)}"
 
+        enter("cpu_baseline")
         if rank == 0 and world == 1:
             result["cpu_baseline"] = cpu_baseline()
 

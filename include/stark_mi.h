@@ -60,7 +60,8 @@ enum {
     /* runtime */
     SMI_ERR_HIP = -100,
     SMI_ERR_NO_DEVICE = -101,
-    SMI_ERR_OOM = -102
+    SMI_ERR_OOM = -102,
+    SMI_ERR_RCCL = -103               /* RCCL (or the caller's collective shim) failed: smi_last_error */
 };
 
 typedef struct smi_ctx smi_ctx;
@@ -292,6 +293,51 @@ int smi_dev_fourstep_twiddle_pack(smi_ctx *ctx, const uint32_t *d_cols, uint32_t
                                   uint32_t c0, uint32_t n_local_cols, uint32_t n_ranks, int inverse, uint64_t offset);
 /* out[c*rows + r] = in[r*cols + c] for a rows x cols matrix of u32 (LDS-tiled). */
 int smi_dev_transpose(smi_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, size_t rows, size_t cols);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI ---------------------------
+ * Fri::commit / Fri::prove (src/fri.rs:105-156, 250-311) over ONE codeword sharded in contiguous
+ * blocks (rank g holds [g*N/G, (g+1)*N/G)), and the build-defined trace -> proof composition of
+ * smi_dev_stark_prove over the G ranks.  Every rank makes the same calls in the same order; the
+ * collectives (all-gather of the G sub-roots per tree, one grouped send/recv per fold and for the
+ * extension's all-to-all, one byte-sum all-reduce of the proof) run inside the library on the
+ * context's stream.  Results are bit-identical to the single-GPU entry points.  World sizes are
+ * powers of two. */
+typedef struct smi_mgpu smi_mgpu;
+#define SMI_MGPU_ID_BYTES 128
+/* rank 0: ncclGetUniqueId; the caller carries the 128 bytes to the other ranks (any channel) */
+int smi_mgpu_unique_id(uint8_t id[SMI_MGPU_ID_BYTES]);
+/* ncclCommInitRank on the context's device; collective over all ranks */
+int smi_mgpu_create(smi_ctx *ctx, const uint8_t id[SMI_MGPU_ID_BYTES], int rank, int world, smi_mgpu **out);
+/* The same prover over caller-supplied collectives (tests without several GPUs, other transports).
+ * Pointers are device memory; the library drains its stream before each call and expects the
+ * operation to have completed on return (0 = ok).  exchange: the k-th send to a peer matches that
+ * peer's k-th recv from this rank. */
+typedef struct {
+    void *user;
+    int (*all_gather)(void *user, const void *d_send, void *d_recv, size_t bytes_per_rank);
+    int (*exchange)(void *user, int n_send, const int *send_peer, void *const *d_send, const size_t *send_bytes, int n_recv,
+                    const int *recv_peer, void *const *d_recv, const size_t *recv_bytes);
+    int (*all_reduce_sum_u8)(void *user, void *d_buf, size_t bytes);
+} smi_mgpu_coll;
+int smi_mgpu_create_with(smi_ctx *ctx, const smi_mgpu_coll *ops, int rank, int world, smi_mgpu **out);
+void smi_mgpu_destroy(smi_mgpu *m);
+/* blocks shorter than this are all-gathered and the remaining rounds run replicated (default 2^18) */
+int smi_mgpu_set_min_block(smi_mgpu *m, size_t min_block);
+/* Fri::commit: d_block = this rank's block of the initial codeword (device u32).  roots: R x 32,
+ * alphas: R-1 unreduced u64, last codeword as u64 -- on every rank. */
+int smi_mgpu_fri_commit(smi_mgpu *m, const smi_fri_cfg *cfg, const uint32_t *d_block, size_t block_len, uint8_t *roots, uint64_t *alphas,
+                        uint64_t *last_codeword, size_t *last_len);
+/* Fri::prove: the serialized ProofStream (smi_free) and the top-level indices on every rank. */
+int smi_mgpu_fri_prove(smi_mgpu *m, const smi_fri_cfg *cfg, const uint32_t *d_block, size_t block_len, uint8_t **proof, size_t *proof_len,
+                       uint64_t *top_indices);
+/* The extension of smi_dev_lde sharded by (column, coset) units (n_cols << log_blowup and 2^log_n
+ * multiples of the world size, log_blowup <= 4): d_trace_cols = the whole trace on every rank;
+ * d_out_blocks gets this rank's natural-order block of every column (n_cols x N/G, stride N/G). */
+int smi_mgpu_lde(smi_mgpu *m, const uint32_t *d_trace_cols, uint32_t n_cols, uint32_t log_n, uint32_t log_blowup, uint64_t trace_offset,
+                 uint64_t lde_offset, uint32_t *d_out_blocks);
+/* smi_dev_stark_prove (column trees) over the G ranks: same column roots, same proof bytes. */
+int smi_mgpu_stark_prove(smi_mgpu *m, const smi_stark_cfg *cfg, const uint32_t *d_trace_cols, uint8_t *column_roots, uint8_t **proof,
+                         size_t *proof_len, uint64_t *top_indices);
 
 #ifdef __cplusplus
 }

@@ -6,6 +6,7 @@
 
 #include "hash_core.h"
 #include "internal.h"
+#include "lde_core.h"
 
 int launch_leaf_hash(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_digests);
 int launch_combine(smi_ctx *ctx, const uint8_t *d_in, size_t n_pairs, uint8_t *d_out);
@@ -43,6 +44,7 @@ const char *smi_status_string(int status) {
     case SMI_ERR_HIP: return "HIP runtime error";
     case SMI_ERR_NO_DEVICE: return "no usable HIP device";
     case SMI_ERR_OOM: return "out of memory";
+    case SMI_ERR_RCCL: return "RCCL / collective error";
     default: return "unknown status";
     }
 }
@@ -535,6 +537,10 @@ int smi_dev_lde(smi_ctx *ctx, const uint32_t *d_cols, uint32_t n_cols, uint32_t 
     // scaling, so the forward transform runs with offset 1 and reads the n coefficients from
     // the head of each output column (zero-padded to N on the fly).
     SMI_TRY(dev_ntt(ctx, d_cols, d_out, log_n, n, n_cols, n, N, 1, trace_offset, lde_offset));
+    // the extension's zero padding lets it run in two passes over the outputs instead of three
+    // (lde_core.h); SMI_LDE_GENERIC=1 keeps the generic transform (tuning / comparison runs)
+    static const bool generic = getenv("SMI_LDE_GENERIC") && atoi(getenv("SMI_LDE_GENERIC"));
+    if (!generic && lde2_supported(log_n, log_blowup)) return dev_lde2(ctx, d_out, d_out, log_n, log_blowup, n_cols, N, N);
     return dev_ntt(ctx, d_out, d_out, log_N, n, n_cols, N, N, 0, 1, 1);
 }
 

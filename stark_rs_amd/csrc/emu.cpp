@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "ntt_driver.h"
+#include "lde_core.h"
 #include "tables.h"
 
 namespace {
@@ -127,6 +128,75 @@ extern "C" int emu_ntt(uint64_t p, uint64_t g, const uint32_t *in, uint32_t *out
     rq.L = L; rq.n_in = n_in; rq.batch = batch; rq.in_stride = in_stride; rq.out_stride = out_stride; rq.F = F;
     EmuLauncher ln;
     return ntt_run(ln, rq) ? 0 : -1;
+}
+
+// ---- two-pass low-degree extension (lde_core.h): the kernels' phases, one "thread" at a time
+template <int LOGR, int CAP> void emu_lde_a(const LdeArgs &a) {
+    typedef LdeA<LOGR, CAP> A;
+    std::vector<uint32_t> tile(A::R * 4);
+    std::vector<Tw2> tw(A::TWS);
+    for (uint32_t b = 0; b < a.batch; b++)
+        for (uint32_t blk = 0; blk < a.n_tiles; blk++) {
+            const typename A::TileId t = A::tile_id(a, blk);
+            std::vector<std::array<uint32_t, 16>> regs(A::NT);
+            for (uint32_t tid = 0; tid < A::NT; tid++) A::load_tw(a, tw.data(), tid);
+            for (uint32_t tid = 0; tid < A::NT; tid++) A::load_regs(a, t, b, reinterpret_cast<uint32_t(&)[16]>(regs[tid]), tid);
+            for (uint32_t tid = 0; tid < A::NT; tid++) A::step0(a, reinterpret_cast<uint32_t(&)[16]>(regs[tid]), tile.data(), tw.data(), tid);
+            for (uint32_t tid = 0; tid < A::NT; tid++) A::step_mid(a, tile.data(), tw.data(), tid);
+            for (uint32_t tid = 0; tid < A::NT; tid++) A::last_step_store(a, t, b, tile.data(), tw.data(), tid);
+        }
+}
+template <int CAP> void emu_lde_b(const LdeArgs &a) {
+    typedef LdeB<CAP> B;
+    std::vector<uint32_t> tile(B::R * B::WP);
+    std::vector<Tw2> tw(B::R);
+    for (uint32_t b = 0; b < a.batch; b++)
+        for (uint32_t blk = 0; blk < a.n_tiles; blk++) {
+            const typename B::TileId t = B::tile_id(a, blk);
+            for (uint32_t tid = 0; tid < B::NT; tid++) B::load_tw(a, tw.data(), tid);
+            for (uint32_t tid = 0; tid < B::NT; tid++) {
+                uint32_t v[16];
+                B::load(a, t, b, v, tid);
+                B::to_lds(a, v, tile.data(), tid);
+            }
+            for (uint32_t tid = 0; tid < B::NT; tid++) B::step0(a, tile.data(), tw.data(), tid);
+            for (uint32_t tid = 0; tid < B::NT; tid++) B::step_mid(a, tile.data(), tw.data(), tid);
+            for (uint32_t tid = 0; tid < B::NT; tid++) B::last_step_store(a, t, b, tile.data(), tw.data(), tid);
+        }
+}
+// coef: batch columns of 2^L coefficients (stride 2^L); out: batch columns of 2^(L+beta) evaluations
+// on the subgroup of that order (offset 1: the coset shift is applied to the coefficients upstream)
+extern "C" int emu_lde2(uint64_t p, uint64_t g, const uint32_t *coef, uint32_t *out, uint32_t L, uint32_t beta, uint32_t batch) {
+    FieldSetup fs;
+    if (!field_setup(p, g, &fs) || L + beta > fs.K || !lde2_supported(L, beta)) return -1;
+    const Fp &F = fs.F;
+    GeomSpec sp[3];
+    ntt_table_specs(fs, 0, sp);
+    std::vector<uint32_t> tw10 = fill(sp[0], F), lo = fill(sp[1], F), hi = fill(sp[2], F);
+    std::vector<uint32_t> mid((size_t)batch << (L + beta)), coef_t((size_t)batch << L);
+    LdeArgs a;
+    memset(&a, 0, sizeof a);
+    a.coef = coef; a.mid = mid.data(); a.coef_t = coef_t.data(); a.out = out; a.coef_stride = 1ull << L; a.out_stride = 1ull << (L + beta);
+    a.F = F; a.T = NttTables{(const Tw2 *)tw10.data(), lo.data(), hi.data(), fs.K, ntt_table_h(fs.K)};
+    a.L = L; a.beta = beta; a.batch = batch;
+    const bool wide = F.p < (1u << 29);
+    const int logr = (int)L - SMI_LDE_LOGB;
+    {
+        std::vector<uint32_t> tile(LdeCoefTile::T * (LdeCoefTile::T + 1) * 4);
+        for (uint32_t b = 0; b < batch; b++)
+            for (uint32_t by = 0; by < (1u << logr) / LdeCoefTile::T; by++)
+                for (uint32_t bx = 0; bx < 256 / LdeCoefTile::T; bx++) {
+                    for (uint32_t tid = 0; tid < LdeCoefTile::NT; tid++) LdeCoefTile::load(a, bx, by, b, tile.data(), tid);
+                    for (uint32_t tid = 0; tid < LdeCoefTile::NT; tid++) LdeCoefTile::store(a, bx, by, b, tile.data(), tid);
+                }
+    }
+    a.n_tiles = 256u << beta;
+#define LA(LR) if (logr == LR) { if (wide) emu_lde_a<LR, 8>(a); else emu_lde_a<LR, 4>(a); }
+    LA(10) LA(11) LA(12)
+#undef LA
+    a.n_tiles = 1u << (L + beta - SMI_LDE_LOGB - SMI_LDE_BLINES_LOG);
+    if (wide) emu_lde_b<8>(a); else emu_lde_b<4>(a);
+    return 0;
 }
 
 // ---- hash phases (hash_core.h) --------------------------------------------------------

@@ -214,6 +214,35 @@ __global__ void emit_codeword_kernel(const uint32_t *cw, uint64_t len, uint8_t *
     if (i < len) put_u64(dst + 9 + 8 * i, cw[i]);
 }
 
+// launchers for the multi-GPU round loop (mgpu.hip), which sequences the same kernels
+size_t fri_fs_bytes() { return sizeof(FsState); }
+int launch_fs_init(smi_ctx *ctx, void *fs) {
+    fs_init_kernel<<<1, 64, 0, ctx->stream>>>((FsState *)fs);
+    HIP_TRY(ctx, hipGetLastError());
+    return SMI_OK;
+}
+int launch_fs_round(smi_ctx *ctx, void *fs, const uint8_t *root, uint8_t *proof_slot, uint64_t *alpha_out) {
+    fs_round_kernel<<<1, 64, 0, ctx->stream>>>((FsState *)fs, (const uint32_t *)root, proof_slot, alpha_out);
+    HIP_TRY(ctx, hipGetLastError());
+    return SMI_OK;
+}
+int launch_fs_challenge(smi_ctx *ctx, const void *fs, uint64_t *out) {
+    fs_challenge_kernel<<<1, 64, 0, ctx->stream>>>((const FsState *)fs, out);
+    HIP_TRY(ctx, hipGetLastError());
+    return SMI_OK;
+}
+int launch_sample_indices(smi_ctx *ctx, const uint64_t *challenge, uint64_t size, uint64_t reduced_size, uint32_t number,
+                          uint64_t *indices, uint64_t *reduced) {
+    sample_indices_kernel<<<1, 64, 0, ctx->stream>>>(challenge, size, reduced_size, number, indices, reduced);
+    HIP_TRY(ctx, hipGetLastError());
+    return SMI_OK;
+}
+int launch_emit_codeword(smi_ctx *ctx, const uint32_t *cw, uint64_t len, uint8_t *dst) {
+    emit_codeword_kernel<<<(uint32_t)((len + 255) / 256), 256, 0, ctx->stream>>>(cw, len, dst);
+    HIP_TRY(ctx, hipGetLastError());
+    return SMI_OK;
+}
+
 // ------------------------------------------------------------------------- host side
 int smi_fri_num_rounds(const smi_fri_cfg *cfg, uint64_t *rounds) {
     if (!cfg || !rounds) return SMI_ERR_BAD_ARG;
@@ -282,7 +311,7 @@ void smi_fri_run_free(smi_fri_run *run) {
 
 // Folds `count` outputs starting at global index i0 of a codeword of length full_len:
 // out[k] = fold(lo[k], hi[k]) where lo[k] = c[i0+k], hi[k] = c[i0+k+full_len/2].
-static int launch_fold_shard(smi_ctx *ctx, const uint32_t *d_lo, const uint32_t *d_hi, size_t count, size_t i0, size_t full_len,
+int launch_fold_shard(smi_ctx *ctx, const uint32_t *d_lo, const uint32_t *d_hi, size_t count, size_t i0, size_t full_len,
                              const uint64_t *d_alpha, uint64_t offset, uint64_t omega, uint32_t *d_out) {
     const uint32_t p = ctx->fs.F.p;
     if (full_len < 2 || !is_pow2(full_len)) return smi_fail(ctx, SMI_ERR_BAD_ARG, "fold: codeword length must be a power of two >= 2");

@@ -109,6 +109,8 @@ int launch_narrow(smi_ctx *ctx, const uint64_t *d_in, uint32_t *d_out, size_t n,
 int launch_widen(smi_ctx *ctx, const uint32_t *d_in, uint64_t *d_out, size_t n);
 int dev_ntt(smi_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint32_t log_n, size_t n_in, uint32_t batch,
             size_t in_stride, size_t out_stride, int inverse, uint64_t offset, uint64_t post_scale);
+int dev_lde2(smi_ctx *ctx, const uint32_t *d_coef, uint32_t *d_out, uint32_t log_n, uint32_t log_blowup, uint32_t batch,
+             size_t coef_stride, size_t out_stride);
 int check_flag(smi_ctx *ctx);  // syncs; SMI_ERR_NON_CANONICAL if a narrow kernel saw a value >= p
 // caller's (pageable) u64 buffers <-> device u32 residues; synchronous on return
 int host_to_dev_u32(smi_ctx *ctx, const uint64_t *host, size_t n, uint32_t *d_out, int reduce);

@@ -6,6 +6,7 @@
 // roofline that bounds it are described in ntt_core.h and DESIGN.md.
 #include "internal.h"
 #include "ntt_driver.h"
+#include "lde_core.h"
 
 // ------------------------------------------------------------------------- kernels
 // One workgroup per (tile, column).  Tried and dropped (r01, measured on MI355X): persistent
@@ -82,6 +83,55 @@ __global__ __launch_bounds__(1 << (LOGR + LOGW - 4)) void ntt_copy_probe_kernel(
         for (int kk = 0; kk < NP::RL; kk++) st32(out, o0 + ((uint32_t)kk << (KSTEP_LOG + sh)), v[bi * NP::RL + kk] + 1u);
     }
 }
+
+// Two-pass low-degree extension (lde_core.h): coefficient regrouping, pass A per (input tile, coset),
+// pass B per 16 lines.
+__global__ __launch_bounds__(256) void lde_coef_tile_kernel(const LdeArgs a) {
+    __shared__ uint32_t tile[LdeCoefTile::T * (LdeCoefTile::T + 1) * 4];
+    LdeCoefTile::load(a, blockIdx.x, blockIdx.y, blockIdx.z, tile, threadIdx.x);
+    __syncthreads();
+    LdeCoefTile::store(a, blockIdx.x, blockIdx.y, blockIdx.z, tile, threadIdx.x);
+}
+template <int LOGR, int CAP>
+__global__ __launch_bounds__(1 << (LOGR - 2)) void lde_a_kernel(const LdeArgs a) {
+    typedef LdeA<LOGR, CAP> A;
+    __shared__ uint32_t tile[A::R * 4];
+    __shared__ Tw2 tw[A::TWS];
+    const uint32_t tid = threadIdx.x, batch = blockIdx.y;
+    const typename A::TileId t = A::tile_id(a, blockIdx.x);
+    A::load_tw(a, tw, tid);
+    uint32_t v[A::V];
+    A::load_regs(a, t, batch, v, tid);
+    __syncthreads();
+    A::step0(a, v, tile, tw, tid);
+    __syncthreads();
+    A::step_mid(a, tile, tw, tid);
+    __syncthreads();
+    A::last_step_store(a, t, batch, tile, tw, tid);
+}
+template <int CAP>
+__global__ __launch_bounds__(1024) void lde_b_kernel(const LdeArgs a) {
+    typedef LdeB<CAP> B;
+    __shared__ uint32_t tile[B::R * B::WP];
+    __shared__ Tw2 tw[B::R];
+    const uint32_t tid = threadIdx.x, batch = blockIdx.y;
+    const typename B::TileId t = B::tile_id(a, blockIdx.x);
+    B::load_tw(a, tw, tid);
+    uint32_t v[B::V];
+    B::load(a, t, batch, v, tid);
+    B::to_lds(a, v, tile, tid);
+    __syncthreads();
+    B::step0(a, tile, tw, tid);
+    __syncthreads();
+    B::step_mid(a, tile, tw, tid);
+    __syncthreads();
+    B::last_step_store(a, t, batch, tile, tw, tid);
+}
+
+template <int LOGR> __global__ __launch_bounds__(1 << (LOGR - 2)) void lde_a_probe_kernel(const LdeArgs a) {
+    LdeAProbe<LOGR>::run(a, blockIdx.x, blockIdx.y, threadIdx.x);
+}
+__global__ __launch_bounds__(1024) void lde_b_probe_kernel(const LdeArgs a) { LdeBProbe::run(a, blockIdx.x, blockIdx.y, threadIdx.x); }
 
 __global__ __launch_bounds__(SMI_NTT_THREADS) void ntt_small_kernel(const SmallArgs a) {
     __shared__ uint32_t buf[SMI_TILE + SMI_TILE / 64];
@@ -211,6 +261,71 @@ struct HipLauncher {
     }
 };
 }  // namespace
+
+// Extension of `batch` coefficient columns (n = 2^log_n each, already scaled by the coset offset's
+// powers) to N = n << log_blowup evaluations in two passes; d_coef may be the head of d_out's columns.
+int dev_lde2(smi_ctx *ctx, const uint32_t *d_coef, uint32_t *d_out, uint32_t log_n, uint32_t log_blowup, uint32_t batch,
+             size_t coef_stride, size_t out_stride) {
+    if (!lde2_supported(log_n, log_blowup) || log_n + log_blowup > ctx->fs.K) return smi_fail(ctx, SMI_ERR_BAD_ARG, "lde2: unsupported shape");
+    if (!batch) return SMI_OK;
+    if (batch > 65535) return smi_fail(ctx, SMI_ERR_BAD_ARG, "batch too large");
+    const uint32_t logN = log_n + log_blowup;
+    LdeArgs a;
+    memset(&a, 0, sizeof a);
+    a.coef = d_coef; a.out = d_out; a.coef_stride = coef_stride; a.out_stride = out_stride;
+    a.F = ctx->fs.F; a.T = ctx_tables(ctx, 0); a.L = log_n; a.beta = log_blowup; a.batch = batch;
+    SMI_TRY(ctx_scratch(ctx, ((size_t)batch << logN) + ((size_t)batch << log_n), &a.mid));
+    a.coef_t = a.mid + ((size_t)batch << logN);
+    const bool wide = a.F.p < (1u << 29);
+    const double n = (double)(1ull << log_n), N = (double)(1ull << logN);
+    static const uint32_t dbg = getenv("SMI_LDE_DBG") ? (uint32_t)atoi(getenv("SMI_LDE_DBG")) : 0u;   // tuning runs only
+    a.dbg = dbg;
+    const int logr = (int)log_n - SMI_LDE_LOGB;
+    {
+        ProfScope ps(ctx, "lde_coef_tile_kernel", 8.0 * n * batch);
+        lde_coef_tile_kernel<<<dim3(256 / LdeCoefTile::T, (1u << logr) / LdeCoefTile::T, batch), LdeCoefTile::NT, 0, ctx->stream>>>(a);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    if (ctx->copy_probe) {   // the copy-only twins of both passes (bench.py's pattern-copy figure)
+        a.n_tiles = 256u << log_blowup;
+        {
+            ProfScope ps(ctx, logr == 12 ? "lde_copy_probe_a<12>" : logr == 11 ? "lde_copy_probe_a<11>" : "lde_copy_probe_a<10>", (4.0 * n + 4.0 * N) * batch);
+            const dim3 grid(a.n_tiles, batch);
+            if (logr == 10) lde_a_probe_kernel<10><<<grid, 256, 0, ctx->stream>>>(a);
+            if (logr == 11) lde_a_probe_kernel<11><<<grid, 512, 0, ctx->stream>>>(a);
+            if (logr == 12) lde_a_probe_kernel<12><<<grid, 1024, 0, ctx->stream>>>(a);
+        }
+        a.n_tiles = 1u << (logN - SMI_LDE_LOGB - SMI_LDE_BLINES_LOG);
+        {
+            ProfScope ps(ctx, "lde_copy_probe_b", 8.0 * N * batch);
+            lde_b_probe_kernel<<<dim3(a.n_tiles, batch), 1024, 0, ctx->stream>>>(a);
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        return SMI_OK;
+    }
+    {
+        a.n_tiles = 256u << log_blowup;
+        const dim3 grid(a.n_tiles, batch);
+        ProfScope ps(ctx, logr == 12 ? "lde_a_kernel<12>" : logr == 11 ? "lde_a_kernel<11>" : "lde_a_kernel<10>", (4.0 * n + 4.0 * N) * batch);
+#define LA(LR)                                                                                     \
+    if (logr == LR) {                                                                              \
+        if (wide) lde_a_kernel<LR, 8><<<grid, 1 << (LR - 2), 0, ctx->stream>>>(a);                 \
+        else lde_a_kernel<LR, 4><<<grid, 1 << (LR - 2), 0, ctx->stream>>>(a);                      \
+    }
+        LA(10) LA(11) LA(12)
+#undef LA
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    {
+        a.n_tiles = 1u << (logN - SMI_LDE_LOGB - SMI_LDE_BLINES_LOG);
+        const dim3 grid(a.n_tiles, batch);
+        ProfScope ps(ctx, "lde_b_kernel", 8.0 * N * batch);
+        if (wide) lde_b_kernel<8><<<grid, 1024, 0, ctx->stream>>>(a);
+        else lde_b_kernel<4><<<grid, 1024, 0, ctx->stream>>>(a);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    return SMI_OK;
+}
 
 int dev_ntt(smi_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint32_t log_n, size_t n_in, uint32_t batch,
             size_t in_stride, size_t out_stride, int inverse, uint64_t offset, uint64_t post_scale) {

@@ -42,6 +42,12 @@ __global__ void fs_weights_kernel(const uint8_t *const *root_ptrs, uint32_t n, u
     }
 }
 
+int launch_fs_weights(smi_ctx *ctx, const uint8_t *const *d_root_ptrs, uint32_t n, uint64_t *weights, uint8_t *roots_out) {
+    fs_weights_kernel<<<1, 64, 0, ctx->stream>>>(d_root_ptrs, n, weights, (uint32_t *)roots_out);
+    HIP_TRY(ctx, hipGetLastError());
+    return SMI_OK;
+}
+
 // row-leaf variant: a single root enters the transcript; weight c = FiatShamir::challenge of the
 // transcript root || c as LE u64 (absorb(root); absorb(c.to_le_bytes()); challenge() on a clone)
 __global__ void fs_row_weights_kernel(const uint8_t *root, uint32_t n, uint64_t *weights, uint8_t *roots_out) {

@@ -173,3 +173,41 @@ def test_emulated_ntt_batched_4096_point_columns_use_pass_kernels(emu, oracle):
     got = _ntt(emu, P, G, cols, L, n, 0, 5, batch=batch).reshape(batch, n)
     for c in (0, 63):
         assert np.array_equal(got[c], o.fast_coset_ntt(cols[c * n:(c + 1) * n], n, w, 5))
+
+
+def _lde2(emu, p, g, coef, L, beta, batch=1):
+    coef = np.ascontiguousarray(coef, dtype=np.uint32)
+    out = np.zeros(batch << (L + beta), dtype=np.uint32)
+    emu.emu_lde2.argtypes = [C.c_uint64, C.c_uint64, u32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32]
+    rc = emu.emu_lde2(p, g, coef.ctypes.data_as(u32p), out.ctypes.data_as(u32p), L, beta, batch)
+    assert rc == 0
+    return out.astype(np.uint64)
+
+
+# two-pass low-degree extension (csrc/lde_core.h): every line size of pass A (2^10, 2^11, 2^12) and
+# every coset/line split of pass B (blowup 2..16), both lazy ranges, against Polynomial::eval_domain's
+# fast restatement on the blowup subgroup (src/univariate/eval.rs:16-21)
+@pytest.mark.parametrize("p,g,L,beta", [(P, G, 20, 1), (P, G, 20, 2), (P, G, 20, 3), (P2, G2, 20, 4), (P2, G2, 21, 3),
+                                        (P2, G2, 22, 3), (P, G, 22, 1)])
+def test_emulated_two_pass_lde(emu, oracle, p, g, L, beta):
+    o = oracle
+    n, N = 1 << L, 1 << (L + beta)
+    W = o.ff_prim_nth_root_g(N, p, g)
+    coef = o.splitmix64(31 * L + beta, n) % np.uint64(p)
+    assert np.array_equal(_lde2(emu, p, g, coef, L, beta), o.fast_coset_ntt(coef, N, W, 1, p))
+
+
+def test_emulated_two_pass_lde_extremes_and_batch(emu, oracle):
+    """constant p-1 / alternating inputs drive every lazy sum to its bound (the emulator asserts the
+    claimed ranges); a batch of two columns checks the column strides."""
+    o = oracle
+    L, beta = 20, 3
+    n, N = 1 << L, 1 << (L + beta)
+    for p, g in ((P, G), (P2, G2)):
+        W = o.ff_prim_nth_root_g(N, p, g)
+        a = np.full(n, p - 1, dtype=np.uint64)
+        b = a.copy()
+        b[1::2] = 0
+        got = _lde2(emu, p, g, np.concatenate([a, b]), L, beta, batch=2).reshape(2, N)
+        assert np.array_equal(got[0], o.fast_coset_ntt(a, N, W, 1, p))
+        assert np.array_equal(got[1], o.fast_coset_ntt(b, N, W, 1, p))

@@ -297,3 +297,30 @@ def test_cfg5_shape_on_second_prime(eng2, oracle):
     cfg = o.fri_cfg(Wn, G2, N, 1 << lb, t, P2)
     assert o.fri_num_rounds(cfg) == 18
     assert o.fri_verify(cfg, res["proof"]), o.fri_last_reject()
+
+
+# ---- two-pass low-degree extension (csrc/lde_core.h): smi_dev_lde at the sizes it serves
+@pytest.mark.parametrize("which,logn,lb,W", [("ref", 20, 1, 1), ("ref", 20, 2, 2), ("ref", 20, 3, 4), ("ref", 21, 2, 1),
+                                             ("second", 20, 4, 1), ("second", 21, 3, 2), ("second", 22, 3, 4), ("second", 22, 4, 1)])
+def test_two_pass_lde_equals_oracle(eng, eng2, oracle, which, logn, lb, W):
+    """interpolate_domain on the trace domain, eval_domain on the blowup coset (src/univariate/
+    interpolate.rs:6-44, eval.rs:16-21) -- the oracle's fast restatement of both, whole columns."""
+    o = oracle
+    e, p, g = (eng, P, G) if which == "ref" else (eng2, P2, G2)
+    n, N = 1 << logn, 1 << (logn + lb)
+    w, Wn = o.ff_prim_nth_root_g(n, p, g), o.ff_prim_nth_root_g(N, p, g)
+    cols = np.stack([_vals(o, 900 + 7 * logn + c, n, p) for c in range(W)])
+    if W > 1:
+        cols[1, :] = p - 1                       # lazy sums at their bounds
+    d_in = _upload(e, cols)
+    d_out = e.dev_alloc(W * N * 4)
+    e.profile(True)
+    e.dev_lde(d_in, W, logn, lb, d_out, 1, g)
+    names = e.profile_read()
+    e.profile(False)
+    assert any(k.startswith("lde_a_kernel") for k in names) and "lde_b_kernel" in names, names   # the two-pass path ran
+    got = e.dev_download(d_out, W * N).reshape(W, N)
+    for c in range(W):
+        assert np.array_equal(got[c], o.fast_coset_ntt(o.fast_intt(cols[c], w, 1, p), N, Wn, g, p)), c
+    e.dev_free(d_in)
+    e.dev_free(d_out)

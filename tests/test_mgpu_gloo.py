@@ -1,0 +1,154 @@
+"""CPU, world sizes 2 and 4 over gloo: the multi-GPU round loop that ships in libstarkmi.so
+(csrc/mgpu_loop.h -- smi_mgpu_fri_prove / smi_mgpu_stark_prove / smi_mgpu_lde run it over HIP + RCCL)
+instantiated over host memory by the emulator library (csrc/emu_mgpu.cpp, the kernels' own
+per-thread code), with the collectives supplied through the smi_mgpu_coll shim as gloo calls.
+
+Checked against the oracle's single-process Fri::prove (reference src/fri.rs:250-311) and the
+single-process composition of csrc/stark.hip: the serialized proof must be byte-identical on EVERY
+rank (the proof is assembled by a byte-sum all-reduce of what each rank owns)."""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+P, G = 998244353, 3
+u32p = C.POINTER(C.c_uint32)
+
+
+def _emu():
+    import stark_rs_amd as s
+    from stark_rs_amd.mgpu import CollOps
+    from stark_rs_amd._lib import FriCfg, StarkCfg
+    s.build()
+    L = C.CDLL(os.path.join(os.path.dirname(s.__file__), "build", "libstarkmi_emu.so"))
+    sz, vp, i32 = C.c_size_t, C.c_void_p, C.c_int
+    L.emu_mgpu_fri_prove.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(CollOps), i32, i32, C.POINTER(FriCfg), u32p, sz, sz, i32, vp, sz,
+                                     C.POINTER(sz), vp, vp]
+    L.emu_mgpu_stark_prove.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(CollOps), i32, i32, C.POINTER(StarkCfg), u32p, sz, vp, vp, sz,
+                                       C.POINTER(sz), vp]
+    L.emu_mgpu_lde.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(CollOps), i32, i32, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
+                               C.c_uint64, u32p]
+    return L
+
+
+def _init(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from stark_rs_amd.mgpu import HostCollectives, HostMem
+    return _emu(), HostCollectives(rank, world, HostMem())
+
+
+def _fri_worker(rank, world, port, logn, expansion, t, offset, min_block, q):
+    L, coll = _init(rank, world, port)
+    from stark_rs_amd._lib import FriCfg
+    from oracle import oracle as o
+    n = 1 << logn
+    omega = o.ff_prim_nth_root(n)
+    codeword = o.fast_coset_ntt(o.splitmix64(78, n // expansion) % np.uint64(P), n, omega, offset)
+    blk = n // world
+    block = np.ascontiguousarray(codeword[rank * blk:(rank + 1) * blk].astype(np.uint32))
+    cfg = FriCfg(omega, offset, n, expansion, t)
+    proof = (C.c_uint8 * (1 << 22))()
+    plen = C.c_size_t()
+    top = (C.c_uint64 * (t + 1))()
+    alphas = (C.c_uint64 * 64)()
+    rc = L.emu_mgpu_fri_prove(P, G, C.byref(coll.ops), rank, world, C.byref(cfg), block.ctypes.data_as(u32p), blk, min_block, 1,
+                              proof, len(proof), C.byref(plen), top, alphas)
+    ok = rc == 0 and not coll.errors
+    if ok:
+        ocfg = o.fri_cfg(omega, offset, n, expansion, t)
+        want, want_top = o.fri_prove(ocfg, codeword)
+        _roots, walphas, _last = o.fri_commit_trace(ocfg, codeword)
+        ok = bytes(proof[:plen.value]) == want and list(top)[:t] == want_top and list(alphas)[:len(walphas)] == walphas
+        ok = ok and (rank != 0 or o.fri_verify(ocfg, want))
+    q.put((rank, bool(ok), rc, coll.errors))
+    dist.destroy_process_group()
+
+
+def _stark_worker(rank, world, port, logn, lb, W, t, min_block, q):
+    L, coll = _init(rank, world, port)
+    from stark_rs_amd._lib import StarkCfg
+    from oracle import oracle as o
+    n, N = 1 << logn, 1 << (logn + lb)
+    w, Wn = o.ff_prim_nth_root(n), o.ff_prim_nth_root(N)
+    cols = np.stack([o.splitmix64(0x5354524B00 + c, n) % np.uint64(P) for c in range(W)])
+    trace = np.ascontiguousarray(cols.reshape(-1).astype(np.uint32))
+    cfg = StarkCfg(logn, lb, W, 0, 1, G, t)
+    roots = (C.c_uint8 * (32 * W))()
+    proof = (C.c_uint8 * (1 << 22))()
+    plen = C.c_size_t()
+    top = (C.c_uint64 * (t + 1))()
+    rc = L.emu_mgpu_stark_prove(P, G, C.byref(coll.ops), rank, world, C.byref(cfg), trace.ctypes.data_as(u32p), min_block, roots,
+                                proof, len(proof), C.byref(plen), top)
+    ok = rc == 0 and not coll.errors
+    if ok:
+        # the single-process composition, stage by stage (what tests/test_gpu_pipeline.py checks the
+        # one-GPU smi_dev_stark_prove against)
+        lde = [o.fast_coset_ntt(o.fast_intt(cols[c], w, 1), N, Wn, G) for c in range(W)]
+        # ... and the sharded extension on its own: this rank's block of every column
+        out = np.zeros(W * N // world, dtype=np.uint32)
+        rc2 = L.emu_mgpu_lde(P, G, C.byref(coll.ops), rank, world, trace.ctypes.data_as(u32p), W, logn, lb, 1, G, out.ctypes.data_as(u32p))
+        blk = N // world
+        ok = rc2 == 0 and all(np.array_equal(out[c * blk:(c + 1) * blk].astype(np.uint64), lde[c][rank * blk:(rank + 1) * blk]) for c in range(W))
+        fs, weights, want_roots = o.FiatShamir(), [], []
+        for c in range(W):
+            want_roots.append(o.merkle_commit(o.leaf_hashes(lde[c])))
+            fs.absorb(want_roots[-1])
+            weights.append(fs.challenge() % P)
+        cw = np.zeros(N, dtype=object)
+        for c in range(W):
+            cw = (cw + lde[c].astype(object) * weights[c]) % P
+        ocfg = o.fri_cfg(Wn, G, N, 1 << lb, t)
+        want, want_top = o.fri_prove(ocfg, cw.astype(np.uint64))
+        got_roots = bytes(roots)
+        ok = ok and [got_roots[32 * c:32 * c + 32] for c in range(W)] == [bytes(r) for r in want_roots]
+        ok = ok and bytes(proof[:plen.value]) == want and list(top)[:t] == want_top
+    q.put((rank, bool(ok), rc, coll.errors))
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run(target, world, args):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port) + args + (q,)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(300)
+        assert pr.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(world))
+    assert [g[0] for g in got] == list(range(world))
+    assert all(g[1] for g in got), got          # every rank holds the oracle's bytes
+
+
+@pytest.mark.parametrize("world,logn,expansion,t,offset,min_block", [
+    (2, 10, 4, 4, 3, 64),       # sharded for 3 rounds, then gathered: openings from both ranks' subtrees
+    (4, 11, 8, 8, 7, 32),       # four ranks: lo/hi partners differ, two levels above the sub-roots
+    (2, 8, 4, 2, 3, 1 << 12),   # blocks below min_block from the start: replicated, rank 0 answers every query
+    (4, 9, 4, 4, 5, 2),         # sharded down to 2-element blocks: every round but the last few exchanges
+])
+def test_native_loop_fri_prove_is_byte_identical_on_every_rank(oracle, world, logn, expansion, t, offset, min_block):
+    _run(_fri_worker, world, (logn, expansion, t, offset, min_block))
+
+
+@pytest.mark.parametrize("world,logn,lb,W,t,min_block", [
+    (2, 8, 3, 4, 4, 64),        # 32 (column, coset) units on two ranks: two whole columns each
+    (4, 7, 2, 3, 2, 16),        # 12 units on four ranks: ranks share a column
+    (8, 6, 3, 4, 2, 16),        # BASELINE configs[4]'s shape: 4 columns, blowup 8, 8 ranks -> 4 cosets of one column per rank
+])
+def test_native_loop_stark_prove_equals_single_process_composition(oracle, world, logn, lb, W, t, min_block):
+    _run(_stark_worker, world, (logn, lb, W, t, min_block))
