@@ -145,7 +145,6 @@ def main():
     import torch
     import torch.distributed as dist
     import stark_rs_amd as s
-    from stark_rs_amd.fourstep import FourStepNTT, HipBackend
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -371,93 +370,91 @@ def main():
                 result["cfg3_error"] = str(e)
             e1.close()
 
-        # ---- BASELINE configs[3]: 2^26-point four-step NTT sharded over the N GPUs
-        enter("four_step_2p26")
+        # ---- one codeword / one trace over the N GPUs through the native multi-GPU entry points
+        # (smi_mgpu_*: round loop, kernels and RCCL collectives inside libstarkmi.so)
+        enter("mgpu fri / prove")
         if distributed:
           try:
-            lr, lc = 13, 13
-            fs = FourStepNTT(HipBackend(eng), lr, lc, p, rank, world)
-            ncl = (1 << lc) // world
-            cols = torch.from_numpy((splitmix64(4 + rank, ncl << lr) % np.uint64(p)).astype(np.uint32).view(np.int32)).to(dev)
-            fs.forward(cols.clone(), offset=1)
-            torch.cuda.synchronize()
-            barrier()
-            reps = 10
-            t1 = time.perf_counter()
-            for _ in range(reps):
-                fs.forward(cols, offset=1)
-            torch.cuda.synchronize()
-            barrier()
-            dt = time.perf_counter() - t1
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            result["four_step_2p26"] = {"field_elements_per_s": reps * (1 << 26) / float(tt.item()),
-                                        "ms_per_transform": 1e3 * float(tt.item()) / reps, "scaling": "strong"}
-          except Exception as e:  # an extra: never lose the headline line over it
-            result["four_step_error"] = str(e)
-
-        # ---- one 2^25-point codeword sharded over the N GPUs: Fri::commit with per-rank Merkle
-        # subtrees, all-gathered sub-roots and the pairwise fold exchange
-        enter("sharded fri / prove")
-        if distributed:
-          try:
-            from stark_rs_amd.sharded import HipShardBackend, ShardedFriCommit
+            from stark_rs_amd.mgpu import HipMem, HostCollectives, MultiGpu
             logN = LOG_ROWS + LOG_BLOWUP
             blk = (1 << logN) // world
-            be = HipShardBackend(eng)
-            block = be.tensor(splitmix64(9 + rank, blk) % np.uint64(p))
-            # blocks below 2^18 elements are gathered: from there a round is hash latency, not throughput,
-            # and one rank's tree costs less than the exchange
-            MIN_BLOCK = 1 << 18
-            fc = ShardedFriCommit(be, p, eng.prim_nth_root(1 << logN), s.G2, 1 << logN, 1 << LOG_BLOWUP, N_TESTS, rank, world,
-                                  min_block=MIN_BLOCK)
-            fc.commit(block)
+            # blocks below 2^18 elements are gathered: from there a round is hash latency, not throughput
+            host = None if backend == "nccl" else HostCollectives(rank, world, HipMem())
+            mg = MultiGpu(eng, rank, world, host=host, min_block=1 << 18)
+            omega = eng.prim_nth_root(1 << logN)
+            # self-check before anything is timed: the sharded proof of a 2^20-point codeword must be
+            # byte-identical to the single-GPU proof of the same codeword (rank 0 computes both)
+            chk_n = 1 << 20
+            chk = (splitmix64(11, chk_n) % np.uint64(p)).astype(np.uint32)
+            cfg_c = eng.fri_cfg(eng.prim_nth_root(chk_n), s.G2, chk_n, 1 << LOG_BLOWUP, N_TESTS)
+            d_part = torch.from_numpy(chk[rank * (chk_n // world):(rank + 1) * (chk_n // world)].view(np.int32).copy()).to(dev)
+            got, got_top = mg.fri_prove(cfg_c, d_part.data_ptr(), chk_n // world)
+            d_all = torch.from_numpy(chk.view(np.int32).copy()).to(dev)
+            want = eng.dev_fri_prove(cfg_c, d_all.data_ptr(), chk_n)
+            if bytes(want[0]) != got or list(want[1]) != got_top:
+                print(f"bench.py: rank {rank}: sharded proof differs from the single-GPU proof", file=sys.stderr, flush=True)
+                os._exit(4)
+            result["mgpu_selfcheck"] = "sharded Fri::prove of a 2^20 codeword == single-GPU proof bytes on every rank"
+            # BASELINE configs[3]: ONE 2^26-point transform over the N GPUs (strong scaling): pass 0 on column
+            # strips, one all-to-all over xGMI, the remaining passes (smi_mgpu_ntt)
+            enter("four_step_2p26")
+            L26 = 26
+            strip = torch.from_numpy((splitmix64(4 + rank, (1 << L26) // world) % np.uint64(p)).astype(np.uint32).view(np.int32)).to(dev)
+            work, out26 = torch.empty_like(strip), torch.empty_like(strip)
+            work.copy_(strip)
+            mg.ntt(work.data_ptr(), out26.data_ptr(), L26)
             torch.cuda.synchronize()
             barrier()
-            t1 = time.perf_counter()
-            fc.commit(block)
-            torch.cuda.synchronize()
-            barrier()
-            dt = time.perf_counter() - t1
+            reps, dt = 10, 0.0
+            for _ in range(reps):
+                work.copy_(strip)                 # the transform clobbers its strip; the refill is outside the clock
+                torch.cuda.synchronize()
+                barrier()
+                t1 = time.perf_counter()
+                mg.ntt(work.data_ptr(), out26.data_ptr(), L26)
+                torch.cuda.synchronize()
+                barrier()
+                dt += time.perf_counter() - t1
             tt = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            result["sharded_fri_commit_2p25_ms"] = 1e3 * float(tt.item())
-            # ... and the whole Fri::prove over it (owners open their leaves, rank 0 serializes)
-            from stark_rs_amd.sharded import ShardedFriProve
-            fp = ShardedFriProve(be, p, eng.prim_nth_root(1 << logN), s.G2, 1 << logN, 1 << LOG_BLOWUP, N_TESTS, rank, world,
-                                 min_block=MIN_BLOCK)
-            fp.prove(block)
+            result["four_step_2p26"] = {"field_elements_per_s": reps * (1 << L26) / float(tt.item()),
+                                        "ms_per_transform": 1e3 * float(tt.item()) / reps, "scaling": "strong",
+                                        "path": "pass pipeline + one all-to-all (smi_mgpu_ntt)"}
+            del strip, work, out26
+            enter("mgpu fri / prove")
+            # Fri::prove of one 2^25-point codeword
+            block = torch.from_numpy((splitmix64(9 + rank, blk) % np.uint64(p)).astype(np.uint32).view(np.int32)).to(dev)
+            cfg25 = eng.fri_cfg(omega, s.G2, 1 << logN, 1 << LOG_BLOWUP, N_TESTS)
+            mg.fri_prove(cfg25, block.data_ptr(), blk)
             torch.cuda.synchronize()
             barrier()
             t1 = time.perf_counter()
-            proof, _top = fp.prove(block)
+            proof, _top = mg.fri_prove(cfg25, block.data_ptr(), blk)
             torch.cuda.synchronize()
             barrier()
             dt = time.perf_counter() - t1
             tt = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             result["sharded_fri_prove_2p25_ms"] = 1e3 * float(tt.item())
-            if rank == 0:
-                result["sharded_fri_prove_bytes"] = len(proof)
-            # ... and BASELINE configs[4]: the full prove of ONE 2^22 x 4 trace over the N GPUs (strong
-            # scaling): LDE replicated, column trees and FRI sharded by blocks of leaves
-            from stark_rs_amd.sharded import ShardedStarkProve
+            result["sharded_fri_prove_bytes"] = len(proof)
+            # BASELINE configs[4]: the full prove of ONE 2^22 x 4 trace over the N GPUs (strong scaling):
+            # extension sharded by (column, coset) units, column trees and FRI by blocks of leaves
             one = torch.from_numpy(np.concatenate([(splitmix64(0x5354524B00 + c, n) % np.uint64(p)).astype(np.uint32)
                                                    for c in range(N_COLS)]).view(np.int32)).to(dev)
-            sp = ShardedStarkProve(be, p, s.G2, LOG_ROWS, LOG_BLOWUP, N_COLS, N_TESTS, eng.prim_nth_root(1 << logN), rank, world,
-                                   min_block=MIN_BLOCK)
-            sp.prove(one)
+            for _ in range(2):
+                mg.stark_prove(one.data_ptr(), N_COLS, LOG_ROWS, LOG_BLOWUP, N_TESTS)
             torch.cuda.synchronize()
             barrier()
             t1 = time.perf_counter()
-            _roots, sproof, _top = sp.prove(one)
+            _roots, sproof, _top = mg.stark_prove(one.data_ptr(), N_COLS, LOG_ROWS, LOG_BLOWUP, N_TESTS)
             torch.cuda.synchronize()
             barrier()
             dt = time.perf_counter() - t1
             tt = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            result["sharded_prove_2p22x4_ms"] = {"value": 1e3 * float(tt.item()), "scaling": "strong",
-                                                 "proof_bytes": len(sproof) if rank == 0 else None}
+            result["sharded_prove_2p22x4_ms"] = {"value": 1e3 * float(tt.item()), "scaling": "strong", "proof_bytes": len(sproof),
+                                                 "collectives": "rccl (in-library)" if host is None else "host shim (rehearsal)"}
+            mg.close()
           except Exception as e:
             import traceback
             result["sharded_fri_error"] = f"{type(e).__name__}: {e} | {traceback.format_exc(limit=3)}"

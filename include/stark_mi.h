@@ -335,6 +335,17 @@ int smi_mgpu_fri_prove(smi_mgpu *m, const smi_fri_cfg *cfg, const uint32_t *d_bl
  * d_out_blocks gets this rank's natural-order block of every column (n_cols x N/G, stride N/G). */
 int smi_mgpu_lde(smi_mgpu *m, const uint32_t *d_trace_cols, uint32_t n_cols, uint32_t log_n, uint32_t log_blowup, uint64_t trace_offset,
                  uint64_t lde_offset, uint32_t *d_out_blocks);
+/* ONE transform of 2^log_n points over the G ranks (BASELINE configs[3]; the reference has no NTT, this is
+ * Polynomial::eval_domain / interpolate_domain on a geometric domain of that size, src/univariate/eval.rs:16-21,
+ * interpolate.rs:6-44) on the ordinary pass pipeline with ONE all-to-all.  With R_0 = 2^*log_r0 the
+ * plan's first digit (smi_mgpu_ntt_first_digit) and B = N / R_0:
+ *   d_strip: this rank's columns [rank*B/G, (rank+1)*B/G) of the row-major [R_0][B] view of the input, as
+ *            [R_0][B/G] (clobbered);
+ *   d_out  : N/G outputs, X[k_0 + R_0*rest] at rest*(R_0/G) + (k_0 - rank*R_0/G) -- natural-order runs of R_0/G.
+ * Forward: evaluations on offset*<w_N>; inverse (offset must be 1): coefficients from values.  At G = 1 it is
+ * the direct transform. */
+int smi_mgpu_ntt(smi_mgpu *m, uint32_t *d_strip, uint32_t *d_out, uint32_t log_n, int inverse, uint64_t offset);
+int smi_mgpu_ntt_first_digit(uint32_t log_n, uint32_t *log_r0);
 /* smi_dev_stark_prove (column trees) over the G ranks: same column roots, same proof bytes. */
 int smi_mgpu_stark_prove(smi_mgpu *m, const smi_stark_cfg *cfg, const uint32_t *d_trace_cols, uint8_t *column_roots, uint8_t **proof,
                          size_t *proof_len, uint64_t *top_indices);

@@ -103,6 +103,7 @@ int smi_ctx_create(uint64_t p, uint64_t g, int device, smi_ctx **out) {
 
 void smi_ctx_destroy(smi_ctx *ctx) {
     if (!ctx) return;
+    DeviceGuard dg__(ctx);
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (int d = 0; d < 2; d++)
@@ -126,6 +127,7 @@ void smi_ctx_destroy(smi_ctx *ctx) {
 
 int smi_ctx_set_stream(smi_ctx *ctx, void *hip_stream) {
     if (!ctx) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     ctx->stream = (hipStream_t)hip_stream;
@@ -134,21 +136,25 @@ int smi_ctx_set_stream(smi_ctx *ctx, void *hip_stream) {
 }
 int smi_ctx_sync(smi_ctx *ctx) {
     if (!ctx) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return SMI_OK;
 }
 int smi_ctx_profile(smi_ctx *ctx, int enable) {
     if (!ctx) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     ctx->prof_on = enable != 0;
     return SMI_OK;
 }
 int smi_ctx_copy_probe(smi_ctx *ctx, int enable) {
     if (!ctx) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     ctx->copy_probe = enable != 0;
     return SMI_OK;
 }
 int smi_ctx_profile_read(smi_ctx *ctx, smi_kernel_time *out, size_t cap, size_t *n) {
     if (!ctx || !n || (cap && !out)) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     size_t cnt = 0;
     for (ProfRec &r : ctx->prof) {
@@ -500,21 +506,25 @@ int smi_domain_is_geometric(const smi_ctx *ctx, const uint64_t *domain, size_t n
 // ------------------------------------------------------------------------- device memory
 int smi_dev_alloc(smi_ctx *ctx, size_t bytes, void **d_ptr) {
     if (!ctx || !d_ptr) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     if (hipMalloc(d_ptr, bytes ? bytes : 1) != hipSuccess) return smi_fail(ctx, SMI_ERR_OOM, "hipMalloc");
     return SMI_OK;
 }
 int smi_dev_free(smi_ctx *ctx, void *d_ptr) {
     if (!ctx) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipFree(d_ptr));
     return SMI_OK;
 }
 int smi_dev_upload_u64(smi_ctx *ctx, const uint64_t *host, size_t n, uint32_t *d_out, int reduce) {
     if (!ctx || (!host && n) || (!d_out && n)) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     return host_to_dev_u32(ctx, host, n, d_out, reduce);
 }
 int smi_dev_download_u64(smi_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t *host) {
     if (!ctx || (!host && n) || (!d_in && n)) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     return dev_u32_to_host(ctx, d_in, n, host);
 }
 
@@ -522,12 +532,14 @@ int smi_dev_download_u64(smi_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t 
 int smi_dev_ntt(smi_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint32_t log_n, size_t n_in, uint32_t batch,
                 size_t in_stride, size_t out_stride, int inverse, uint64_t offset, uint64_t post_scale) {
     if (!ctx || !d_in || !d_out) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     return dev_ntt(ctx, d_in, d_out, log_n, n_in, batch, in_stride, out_stride, inverse, offset, post_scale);
 }
 
 int smi_dev_lde(smi_ctx *ctx, const uint32_t *d_cols, uint32_t n_cols, uint32_t log_n, uint32_t log_blowup,
                 uint64_t trace_offset, uint64_t lde_offset, uint32_t *d_out) {
     if (!ctx || !d_cols || !d_out) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     const uint32_t log_N = log_n + log_blowup;
     if (log_N > ctx->fs.K) return smi_fail(ctx, ctx->fs.F.p == 998244353u ? SMI_ERR_ROOT_TOO_LARGE : SMI_ERR_UNSUPPORTED_PRIME,
                                            "LDE domain exceeds the two-adicity of the modulus");
@@ -556,12 +568,14 @@ static int host_ntt(smi_ctx *ctx, const uint64_t *in, size_t n_in, uint64_t *out
 
 int smi_intt(smi_ctx *ctx, const uint64_t *values, uint64_t *coeffs, uint32_t log_n, uint64_t offset) {
     if (!ctx || !values || !coeffs) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     if (log_n > 40) return SMI_ERR_BAD_ARG;
     if (offset % ctx->fs.F.p == 0) return smi_fail(ctx, SMI_ERR_NO_INVERSE, "no inverse");  // duplicate domain points, src/ff.rs:171
     return host_ntt(ctx, values, (size_t)1 << log_n, coeffs, log_n, 1, offset);
 }
 int smi_coset_ntt(smi_ctx *ctx, const uint64_t *coeffs, size_t n_coeffs, uint64_t *evals, uint32_t log_N, uint64_t offset) {
     if (!ctx || (!coeffs && n_coeffs) || !evals) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     if (log_N > 40 || n_coeffs > ((size_t)1 << log_N)) return SMI_ERR_BAD_ARG;
     if (offset % ctx->fs.F.p == 0) return smi_fail(ctx, SMI_ERR_BAD_ARG, "coset offset must be nonzero");
     return host_ntt(ctx, coeffs, n_coeffs, evals, log_N, 0, offset);
@@ -575,6 +589,7 @@ __global__ void scale_kernel(const uint32_t *in, uint32_t *out, size_t n, Fp F, 
 }
 int smi_poly_scale(smi_ctx *ctx, const uint64_t *coeffs, size_t n, uint64_t factor, uint64_t *out) {
     if (!ctx || (!coeffs && n) || (!out && n)) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     if (!n) return SMI_OK;
     if (factor >= ctx->fs.F.p) return smi_fail(ctx, SMI_ERR_NON_CANONICAL, "factor must be < p");
     uint32_t L = 0;
@@ -605,6 +620,7 @@ __global__ void pointwise_mul_kernel(uint32_t *a, const uint32_t *b, size_t n, F
 }
 int smi_poly_mul(smi_ctx *ctx, const uint64_t *a, size_t na, const uint64_t *b, size_t nb, uint64_t *out, size_t *n_out) {
     if (!ctx || !n_out || (na && !a) || (nb && !b)) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     // zero operands give the empty polynomial, exactly like mul.rs:7-12 (is_zero = deg == -1)
     bool za = true, zb = true;
     for (size_t i = 0; i < na; i++) za = za && a[i] == 0;
@@ -680,6 +696,7 @@ static int dev_mul_trunc(smi_ctx *ctx, const uint32_t *x, size_t nx, const uint3
 int smi_poly_div(smi_ctx *ctx, const uint64_t *a, size_t na, const uint64_t *b, size_t nb, uint64_t *q, size_t *nq, uint64_t *r,
                  size_t *nr) {
     if (!ctx || !nq || !nr || (na && !a) || (nb && !b)) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     const uint32_t p = ctx->fs.F.p;
     ptrdiff_t da = -1, db = -1;   // Polynomial::deg (src/univariate/mod.rs:37-46)
     for (size_t i = 0; i < na; i++) { if (a[i] >= p) return smi_fail(ctx, SMI_ERR_NON_CANONICAL, "coefficient >= p"); if (a[i]) da = (ptrdiff_t)i; }
@@ -754,6 +771,7 @@ int smi_poly_div(smi_ctx *ctx, const uint64_t *a, size_t na, const uint64_t *b, 
 int smi_lde(smi_ctx *ctx, const uint64_t *cols, uint32_t n_cols, uint32_t log_n, uint32_t log_blowup, uint64_t trace_offset,
             uint64_t lde_offset, uint64_t *out) {
     if (!ctx || !cols || !out || !n_cols) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     if (log_n + log_blowup > ctx->fs.K)
         return smi_fail(ctx, ctx->fs.F.p == 998244353u ? SMI_ERR_ROOT_TOO_LARGE : SMI_ERR_UNSUPPORTED_PRIME, "LDE domain too large");
     const size_t n = (size_t)1 << log_n, N = n << log_blowup;
@@ -779,10 +797,12 @@ int smi_trace_pack(const smi_ctx *ctx, const void *rows_i128, size_t n_rows, siz
 // ------------------------------------------------------------------------- hash / merkle
 int smi_dev_hash_leaves(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_digests) {
     if (!ctx || (n && (!d_elems || !d_digests))) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     return launch_leaf_hash(ctx, d_elems, n, d_digests);
 }
 int smi_dev_merkle_build(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_nodes) {
     if (!ctx || !d_elems || !d_nodes) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     if (n == 0) return smi_fail(ctx, SMI_ERR_EMPTY_LEAVES, nullptr);
     if (!is_pow2(n)) return smi_fail(ctx, SMI_ERR_LEAVES_NOT_POW2, nullptr);
     return launch_merkle(ctx, d_elems, n, d_nodes);
@@ -790,12 +810,14 @@ int smi_dev_merkle_build(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_
 int launch_merkle_rows(smi_ctx *ctx, const uint32_t *d_cols, uint32_t n_cols, size_t col_stride, size_t n, uint8_t *d_nodes);
 int smi_dev_merkle_build_rows(smi_ctx *ctx, const uint32_t *d_cols, uint32_t n_cols, size_t col_stride, size_t n, uint8_t *d_nodes) {
     if (!ctx || !d_cols || !d_nodes) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     if (n == 0) return smi_fail(ctx, SMI_ERR_EMPTY_LEAVES, nullptr);
     if (!is_pow2(n)) return smi_fail(ctx, SMI_ERR_LEAVES_NOT_POW2, nullptr);
     return launch_merkle_rows(ctx, d_cols, n_cols, col_stride, n, d_nodes);
 }
 int smi_dev_merkle_from_digests(smi_ctx *ctx, size_t n, uint8_t *d_nodes) {
     if (!ctx || !d_nodes) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     if (n == 0) return smi_fail(ctx, SMI_ERR_EMPTY_LEAVES, nullptr);
     if (!is_pow2(n)) return smi_fail(ctx, SMI_ERR_LEAVES_NOT_POW2, nullptr);
     return launch_merkle(ctx, nullptr, n, d_nodes);
@@ -803,6 +825,7 @@ int smi_dev_merkle_from_digests(smi_ctx *ctx, size_t n, uint8_t *d_nodes) {
 
 int smi_hash_leaves(smi_ctx *ctx, const uint64_t *elems, size_t n, uint8_t *digests) {
     if (!ctx || (n && (!elems || !digests))) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     if (!n) return SMI_OK;
     void *stage, *d_in, *d_out;
     SMI_TRY(ctx_tmp(ctx, 0, n * 8, &stage));
@@ -816,6 +839,7 @@ int smi_hash_leaves(smi_ctx *ctx, const uint64_t *elems, size_t n, uint8_t *dige
 }
 int smi_hash_combine_pairs(smi_ctx *ctx, const uint8_t *digests, size_t n_pairs, uint8_t *out) {
     if (!ctx || (n_pairs && (!digests || !out))) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     if (!n_pairs) return SMI_OK;
     void *d_in, *d_out;
     SMI_TRY(ctx_tmp(ctx, 1, n_pairs * 64, &d_in));
@@ -828,6 +852,7 @@ int smi_hash_combine_pairs(smi_ctx *ctx, const uint8_t *digests, size_t n_pairs,
 }
 int smi_hash_bytes(smi_ctx *ctx, const uint8_t *msg, size_t len, uint8_t out[32]) {
     if (!ctx || (len && !msg) || !out) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     void *d_in, *d_out;
     SMI_TRY(ctx_tmp(ctx, 1, len + 4, &d_in));
     SMI_TRY(ctx_tmp(ctx, 2, 32, &d_out));
@@ -840,12 +865,14 @@ int smi_hash_bytes(smi_ctx *ctx, const uint8_t *msg, size_t len, uint8_t out[32]
 
 int smi_dev_hash_bytes(smi_ctx *ctx, const uint8_t *d_msg, size_t len, uint8_t *d_out32) {
     if (!ctx || (len && !d_msg) || !d_out32) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     return launch_hash_bytes(ctx, d_msg, len, (uint32_t *)d_out32);
 }
 
 int launch_hash_bytes_batch(smi_ctx *ctx, const uint8_t *d_msgs, size_t n, size_t len, uint32_t *d_out);
 int smi_hash_bytes_batch(smi_ctx *ctx, const uint8_t *msgs, size_t n, size_t msg_len, uint8_t *out) {
     if (!ctx || (n && msg_len && !msgs) || (n && !out)) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     if (!n) return SMI_OK;
     if (n > ((size_t)1 << 24) || msg_len > ((size_t)1 << 20)) return smi_fail(ctx, SMI_ERR_BAD_ARG, "hash_bytes_batch: at most 2^24 messages of 2^20 bytes");
     void *d_in, *d_out;
@@ -871,6 +898,7 @@ static int tree_alloc(smi_ctx *ctx, size_t n, smi_tree **out) {
 }
 int smi_merkle_new(smi_ctx *ctx, const uint8_t *leaves, size_t n, smi_tree **out) {
     if (!ctx || !out || (n && !leaves)) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     smi_tree *t = nullptr;
     SMI_TRY(tree_alloc(ctx, n, &t));
     int rc = SMI_OK;
@@ -886,6 +914,7 @@ int smi_merkle_new(smi_ctx *ctx, const uint8_t *leaves, size_t n, smi_tree **out
 }
 int smi_merkle_from_codeword(smi_ctx *ctx, const uint64_t *codeword, size_t n, smi_tree **out) {
     if (!ctx || !out || (n && !codeword)) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     smi_tree *t = nullptr;
     SMI_TRY(tree_alloc(ctx, n, &t));
     void *d_in;
@@ -902,6 +931,7 @@ int smi_merkle_from_codeword(smi_ctx *ctx, const uint64_t *codeword, size_t n, s
 }
 int smi_merkle_commit(smi_ctx *ctx, const uint8_t *leaves, size_t n, uint8_t root[32]) {
     if (!ctx || !root) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     smi_tree *t = nullptr;
     SMI_TRY(smi_merkle_new(ctx, leaves, n, &t));
     int rc = smi_merkle_root(ctx, t, root);
@@ -910,12 +940,14 @@ int smi_merkle_commit(smi_ctx *ctx, const uint8_t *leaves, size_t n, uint8_t roo
 }
 int smi_merkle_root(smi_ctx *ctx, const smi_tree *t, uint8_t root[32]) {
     if (!ctx || !t || !root) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     HIP_TRY(ctx, hipMemcpyAsync(root, t->d_nodes + (2 * t->n - 2) * 32, 32, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return SMI_OK;
 }
 int smi_merkle_open(smi_ctx *ctx, const smi_tree *t, size_t index, uint8_t *path, size_t *depth) {
     if (!ctx || !t || !path || !depth) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     if (index >= t->n) return smi_fail(ctx, SMI_ERR_INDEX_OOB, nullptr);  // src/merkle.rs:68
     size_t idx = index, off = 0, len = t->n, d = 0;
     while (len > 1) {  // sibling at each level (src/merkle.rs:73-77)
@@ -931,6 +963,7 @@ int smi_merkle_open(smi_ctx *ctx, const smi_tree *t, size_t index, uint8_t *path
 }
 int smi_merkle_level(smi_ctx *ctx, const smi_tree *t, uint32_t level, uint8_t *out, size_t *n_out) {
     if (!ctx || !t || !out) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     if (level > ilog2(t->n)) return smi_fail(ctx, SMI_ERR_INDEX_OOB, nullptr);
     const size_t cnt = t->n >> level, off = 2 * t->n - ((2 * t->n) >> level);
     HIP_TRY(ctx, hipMemcpyAsync(out, t->d_nodes + off * 32, cnt * 32, hipMemcpyDeviceToHost, ctx->stream));
@@ -941,6 +974,7 @@ int smi_merkle_level(smi_ctx *ctx, const smi_tree *t, uint32_t level, uint8_t *o
 int smi_merkle_verify_batch(smi_ctx *ctx, const uint8_t *leaves, const uint64_t *indices, const uint8_t *paths, size_t k, size_t depth,
                             const uint8_t root[32], uint8_t *ok) {
     if (!ctx || !root || (k && (!leaves || !indices || !ok || (depth && !paths)))) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     if (!k) return SMI_OK;
     if (depth > 64) return smi_fail(ctx, SMI_ERR_BAD_ARG, "verify: path deeper than 64");
     const size_t b_leaves = k * 32, b_idx = k * 8, b_paths = k * depth * 32;
@@ -959,6 +993,7 @@ int smi_merkle_verify_batch(smi_ctx *ctx, const uint8_t *leaves, const uint64_t 
 }
 size_t smi_merkle_num_leaves(const smi_tree *t) { return t ? t->n : 0; }
 void smi_merkle_free(smi_tree *t) {
+    DeviceGuard dg__(t ? t->ctx : nullptr);
     if (!t) return;
     if (t->ctx && t->ctx->stream) (void)hipStreamSynchronize(t->ctx->stream);
     if (t->owns) (void)hipFree(t->d_nodes);

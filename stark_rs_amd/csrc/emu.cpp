@@ -130,6 +130,51 @@ extern "C" int emu_ntt(uint64_t p, uint64_t g, const uint32_t *in, uint32_t *out
     return ntt_run(ln, rq) ? 0 : -1;
 }
 
+// ---- one transform sharded over ranks (ntt_driver.h): this rank's two local phases
+namespace {
+struct EmuTables {
+    std::vector<uint32_t> tw10, lo, hi, slo, shi;
+    NttRequest rq;
+};
+bool emu_shard_request(uint64_t p, uint64_t g, uint32_t L, int inverse, uint64_t offset, EmuTables &t) {
+    FieldSetup fs;
+    if (!field_setup(p, g, &fs) || L > fs.K) return false;
+    const Fp &F = fs.F;
+    GeomSpec sp[3], s2[2];
+    ntt_table_specs(fs, inverse, sp);
+    t.tw10 = fill(sp[0], F); t.lo = fill(sp[1], F); t.hi = fill(sp[2], F);
+    memset(&t.rq, 0, sizeof t.rq);
+    t.rq.T = NttTables{(const Tw2 *)t.tw10.data(), t.lo.data(), t.hi.data(), fs.K, ntt_table_h(fs.K)};
+    t.rq.L = L; t.rq.n_in = 1u << L; t.rq.batch = 1; t.rq.F = F;
+    if (!inverse) {
+        t.rq.pre_scale = offset % F.p != 1;
+        t.rq.q_plain = (uint32_t)(offset % F.p);
+        scale_table_specs(F, 1, t.rq.q_plain, L, s2);
+    } else {
+        t.rq.post_scale = true;
+        t.rq.q_plain = 1;
+        scale_table_specs(F, host_powmod((uint32_t)((1ull << L) % F.p), F.p - 2, F.p), 1, L, s2);
+    }
+    t.slo = fill(s2[0], F); t.shi = fill(s2[1], F);
+    t.rq.S = ScaleTables{t.slo.data(), t.shi.data(), scale_table_h(L)};
+    return true;
+}
+}  // namespace
+extern "C" int emu_ntt_shard_first(uint64_t p, uint64_t g, uint32_t *strip, uint32_t L, uint32_t log_g, uint32_t rank, int inverse, uint64_t offset) {
+    EmuTables t;
+    if (!emu_shard_request(p, g, L, inverse, offset, t)) return -1;
+    t.rq.in = strip; t.rq.out = strip;
+    EmuLauncher ln;
+    return ntt_run_shard_first(ln, t.rq, log_g, rank) ? 0 : -1;
+}
+extern "C" int emu_ntt_shard_rest(uint64_t p, uint64_t g, uint32_t *rows, uint32_t *out, uint32_t L, uint32_t log_g, int inverse) {
+    EmuTables t;
+    if (!emu_shard_request(p, g, L, inverse, 1, t)) return -1;
+    t.rq.scratch = rows; t.rq.out = out;
+    EmuLauncher ln;
+    return ntt_run_shard_rest(ln, t.rq, log_g) ? 0 : -1;
+}
+
 // ---- two-pass low-degree extension (lde_core.h): the kernels' phases, one "thread" at a time
 template <int LOGR, int CAP> void emu_lde_a(const LdeArgs &a) {
     typedef LdeA<LOGR, CAP> A;

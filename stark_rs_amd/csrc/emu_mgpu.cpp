@@ -22,6 +22,8 @@ int emu_ntt(uint64_t p, uint64_t g, const uint32_t *in, uint32_t *out, uint32_t 
             uint64_t out_stride, int inverse, uint64_t offset, uint64_t post_scale);
 void emu_leaf_hash(const uint32_t *v, size_t n, uint8_t *out);
 void emu_node_hash(const uint8_t *pairs, size_t n, uint8_t *out);
+int emu_ntt_shard_first(uint64_t p, uint64_t g, uint32_t *strip, uint32_t L, uint32_t log_g, uint32_t rank, int inverse, uint64_t offset);
+int emu_ntt_shard_rest(uint64_t p, uint64_t g, uint32_t *rows, uint32_t *out, uint32_t L, uint32_t log_g, int inverse);
 int emu_fold_shard(uint64_t p, uint64_t g, const uint32_t *lo, const uint32_t *hi, uint32_t count, uint32_t i0, uint32_t full_len,
                    uint64_t alpha, uint64_t offset, uint64_t omega, uint32_t *out);
 }
@@ -183,6 +185,12 @@ struct EmuDev : MgDev {
         }
         return emu_ntt(p, g, src, out, log_n, (uint32_t)n_in, batch, in_stride, out_stride, inverse, offset, post_scale) ? SMI_ERR_BAD_ARG : SMI_OK;
     }
+    int ntt_shard_first(uint32_t *strip, uint32_t log_n, uint32_t log_g, uint32_t rank, int inverse, uint64_t offset) override {
+        return emu_ntt_shard_first(p, g, strip, log_n, log_g, rank, inverse, offset) ? SMI_ERR_BAD_ARG : SMI_OK;
+    }
+    int ntt_shard_rest(uint32_t *rows, uint32_t *out, uint32_t log_n, uint32_t log_g, int inverse) override {
+        return emu_ntt_shard_rest(p, g, rows, out, log_n, log_g, inverse) ? SMI_ERR_BAD_ARG : SMI_OK;
+    }
     int interleave(const uint32_t *in, uint32_t *out, uint32_t n_cols, uint32_t log_b, size_t nq) override {
         const size_t B = (size_t)1 << log_b;
         for (size_t c = 0; c < n_cols; c++)
@@ -265,4 +273,11 @@ extern "C" int emu_mgpu_lde(uint64_t p, uint64_t g, const smi_mgpu_coll *ops, in
     if (rc != SMI_OK) return rc;
     memcpy(out_blocks, blocks, (((size_t)n_cols << (log_n + log_b)) / (size_t)world) * 4);
     return SMI_OK;
+}
+
+extern "C" int emu_mgpu_ntt(uint64_t p, uint64_t g, const smi_mgpu_coll *ops, int rank, int world, uint32_t *strip, uint32_t *out,
+                            uint32_t log_n, int inverse, uint64_t offset) {
+    EmuDev d(p, g);
+    EmuColl c(*ops);
+    return mg_ntt(d, c, rank, world, strip, out, log_n, inverse, offset);
 }

@@ -69,6 +69,7 @@ static uint32_t ilog2u(uint64_t n) {
 int smi_dev_fourstep_twiddle_pack(smi_ctx *ctx, const uint32_t *d_cols, uint32_t *d_send, uint32_t log_r, uint32_t log_c,
                                   uint32_t c0, uint32_t n_local_cols, uint32_t n_ranks, int inverse, uint64_t offset) {
     if (!ctx || !d_cols || !d_send || !n_ranks) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     const uint32_t log_n = log_r + log_c, p = ctx->fs.F.p;
     if (log_n > ctx->fs.K) return smi_fail(ctx, p == 998244353u ? SMI_ERR_ROOT_TOO_LARGE : SMI_ERR_UNSUPPORTED_PRIME, "four-step size exceeds two-adicity");
     if ((n_ranks & (n_ranks - 1)) || ilog2u(n_ranks) > log_r) return smi_fail(ctx, SMI_ERR_BAD_ARG, "n_ranks must be a power of two <= R");
@@ -92,6 +93,7 @@ int smi_dev_fourstep_twiddle_pack(smi_ctx *ctx, const uint32_t *d_cols, uint32_t
 
 int smi_dev_transpose(smi_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, size_t rows, size_t cols) {
     if (!ctx || !d_in || !d_out || d_in == d_out) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     if (!rows || !cols) return SMI_OK;
     const dim3 grid((uint32_t)((cols + 63) / 64), (uint32_t)((rows + 63) / 64));
     if (grid.y > 65535) return smi_fail(ctx, SMI_ERR_BAD_ARG, "transpose: too many rows");

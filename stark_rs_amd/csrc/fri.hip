@@ -292,6 +292,7 @@ static void *run_alloc(smi_fri_run *run, size_t bytes) {
 
 void smi_fri_run_free(smi_fri_run *run) {
     if (!run) return;
+    DeviceGuard dg__(run->ctx);
     if (run->arena) {  // arena memory is recycled by the next arena_reset
         if (run->owns_first && !run->codewords.empty()) {
             (void)hipStreamSynchronize(run->ctx->stream);
@@ -337,6 +338,7 @@ int launch_fold(smi_ctx *ctx, const uint32_t *d_in, size_t len, const uint64_t *
 int smi_dev_fri_fold_shard(smi_ctx *ctx, const uint32_t *d_lo, const uint32_t *d_hi, size_t count, size_t index0, size_t full_len,
                            const uint64_t *d_alpha, uint64_t offset, uint64_t omega, uint32_t *d_out) {
     if (!ctx || !d_lo || !d_hi || !d_alpha || !d_out) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     return launch_fold_shard(ctx, d_lo, d_hi, count, index0, full_len, d_alpha, offset, omega, d_out);
 }
 
@@ -424,13 +426,49 @@ int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, si
     uint32_t omega = (uint32_t)cfg->omega, offset = (uint32_t)cfg->offset;
     const uint32_t *cur = d_codeword;
     uint64_t cur_len = len;
+    // SMI_FRI_TAIL=0 keeps one set of launches per round to the end (comparison runs)
+    static const bool fused_tail = !(getenv("SMI_FRI_TAIL") && atoi(getenv("SMI_FRI_TAIL")) == 0);
     for (uint64_t r = 0; r < R; r++) {
+        if (fused_tail && cur_len <= SMI_FRI_TAIL_MAX_LEN && R - r <= SMI_FRI_TAIL_MAX_ROUNDS) {
+            // every remaining round in one workgroup launch (hash.hip, fri_tail_kernel)
+            FriTailArgs ta;
+            memset(&ta, 0, sizeof ta);
+            ta.n_rounds = (uint32_t)(R - r);
+            ta.fs_words = d_fs->s;
+            ta.F = ctx->fs.F;
+            ta.inv2_m = (uint32_t)(((uint64_t)h_inv(ctx, 2) << 32) % p);
+            for (uint64_t k = r; k < R; k++) {
+                FriTailRound &tr = ta.r[k - r];
+                const bool last = k == R - 1;
+                tr.cw = cur;
+                tr.len = (uint32_t)cur_len;
+                run->codewords.push_back(const_cast<uint32_t *>(cur));
+                run->lens.push_back(cur_len);
+                tr.nodes = (uint8_t *)run_alloc(run, (2 * cur_len - 1) * 32);
+                if (!tr.nodes) return bail(smi_fail(ctx, SMI_ERR_OOM, "alloc tree"));
+                run->trees.push_back(tr.nodes);
+                tr.proof_slot = run->d_proof + off_roots + 33 * k;
+                tr.alpha_out = last ? nullptr : d_alphas + k;
+                if (last) break;
+                if (cur_len < 2) return bail(smi_fail(ctx, SMI_ERR_BAD_ARG, "fold: codeword length must be a power of two >= 2"));
+                if (offset == 0 || omega == 0) return bail(smi_fail(ctx, SMI_ERR_DIV_BY_ZERO, "no division by zero"));   // src/ff.rs:182
+                if ((rc = ctx_scale_tables(ctx, h_inv(ctx, offset), h_inv(ctx, omega), ilog2(cur_len / 2), &tr.S)) != SMI_OK) return bail(rc);
+                tr.next = (uint32_t *)run_alloc(run, (cur_len / 2) * 4);
+                if (!tr.next) return bail(smi_fail(ctx, SMI_ERR_OOM, "alloc codeword"));
+                cur = tr.next;
+                cur_len /= 2;
+                omega = h_mul(ctx, omega, omega);    // src/fri.rs:146-147
+                offset = h_mul(ctx, offset, offset);
+            }
+            if ((rc = launch_fri_tail(ctx, ta)) != SMI_OK) return bail(rc);
+            break;
+        }
         // leaf hashes + tree (src/fri.rs:118-127); power-of-two lengths never need padding
+        run->codewords.push_back(const_cast<uint32_t *>(cur));   // owned by the run from here on: nothing below can leak it
+        run->lens.push_back(cur_len);
         uint8_t *nodes = (uint8_t *)run_alloc(run, (2 * cur_len - 1) * 32);
         if (!nodes) return bail(smi_fail(ctx, SMI_ERR_OOM, "alloc tree"));
         run->trees.push_back(nodes);
-        run->codewords.push_back(const_cast<uint32_t *>(cur));
-        run->lens.push_back(cur_len);
         const uint32_t *root = (const uint32_t *)(nodes + (2 * cur_len - 2) * 32);
         const bool last = r == R - 1;
         // push root, absorb, challenge (src/fri.rs:129-138): done by the workgroup that finishes the tree
@@ -521,12 +559,14 @@ int smi_fri_run_open(smi_fri_run *run, size_t round, size_t index, uint8_t *path
 int smi_dev_fri_fold(smi_ctx *ctx, const uint32_t *d_in, size_t len, const uint64_t *d_alpha, uint64_t offset,
                      uint64_t omega, uint32_t *d_out) {
     if (!ctx || !d_in || !d_alpha || !d_out) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     return launch_fold(ctx, d_in, len, d_alpha, offset, omega, d_out);
 }
 
 int smi_dev_fri_prove(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, size_t len, uint8_t **proof,
                       size_t *proof_len, uint64_t *top_indices, smi_fri_run **run) {
     if (!ctx || !cfg || !d_codeword || !proof || !proof_len) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     std::vector<uint8_t> bytes;
     SMI_TRY(fri_run(ctx, cfg, d_codeword, len, true, true, run, &bytes, top_indices, nullptr, nullptr, nullptr, nullptr));
     *proof = (uint8_t *)malloc(bytes.size() ? bytes.size() : 1);
@@ -544,6 +584,7 @@ static int upload_codeword(smi_ctx *ctx, const uint64_t *codeword, size_t len, u
 int smi_fri_prove(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint64_t *codeword, size_t len, uint8_t **proof,
                   size_t *proof_len, uint64_t *top_indices) {
     if (!ctx || !cfg || !codeword || !proof || !proof_len) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     SMI_TRY(smi_fri_check(ctx, cfg));
     if (cfg->domain_length != len) return smi_fail(ctx, SMI_ERR_CODEWORD_LEN, "initial codeword length does not match domain length");
     uint32_t *d_cw = nullptr;
@@ -557,6 +598,7 @@ int smi_fri_prove(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint64_t *codeword
 int smi_fri_commit(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint64_t *codeword, size_t len, uint8_t *roots,
                    uint64_t *alphas, uint64_t *last_codeword, size_t *last_len, smi_fri_run **run) {
     if (!ctx || !cfg || !codeword) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     SMI_TRY(smi_fri_check(ctx, cfg));
     if (cfg->domain_length != len) return smi_fail(ctx, SMI_ERR_CODEWORD_LEN, "initial codeword length does not match domain length");
     uint32_t *d_cw = nullptr;
@@ -576,6 +618,7 @@ int smi_fri_commit(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint64_t *codewor
 int smi_fri_fold(smi_ctx *ctx, const uint64_t *codeword, size_t len, uint64_t alpha, uint64_t offset, uint64_t omega,
                  uint64_t *out) {
     if (!ctx || !codeword || !out) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     if (len < 2 || !is_pow2(len)) return smi_fail(ctx, SMI_ERR_BAD_ARG, "fold: codeword length must be a power of two >= 2");
     void *d_in, *d_out, *d_alpha;
     SMI_TRY(ctx_tmp(ctx, 1, len * 4, &d_in));

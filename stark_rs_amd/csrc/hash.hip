@@ -12,6 +12,7 @@
 // thread, conflict free).  merkle_top_kernel: one workgroup finishes a tree from its last
 // <= 2048 digests.  Roofline: integer VALU issue (~0.9k instructions per leaf hash, ~1.2k per node
 // hash), not HBM -- DESIGN.md section 3.
+#include "fri_core.h"
 #include "hash_core.h"
 #include "hash_quad.h"
 #include "internal.h"
@@ -130,16 +131,13 @@ struct TopHook {
     uint8_t *proof_slot;
     uint64_t *alpha_out;
 };
+// One workgroup: leaf digests (FROM_ELEMS) or the digests of level lvl_in for positions [first, first + chunk),
+// then every level above them down to the chunk's root; all of it written to `nodes`.  Returns the
+// slot of each word row of buf ([8][SMI_TOP_MAX]) that holds the root.
 template <bool FROM_ELEMS>
-__global__ __launch_bounds__(SMI_TOP_THREADS) void merkle_top_kernel(const uint32_t *__restrict__ elems, uint4 *nodes, size_t n,
-                                                                      uint32_t lvl_in, uint32_t chunk, size_t elem_stride,
-                                                                      size_t node_stride, uint32_t row_cols, size_t row_stride,
-                                                                      TopHook hook) {
-    __shared__ uint32_t buf[8 * SMI_TOP_MAX];
-    elems += (size_t)blockIdx.y * elem_stride;
-    nodes += (size_t)blockIdx.y * node_stride;
+__device__ __forceinline__ uint32_t top_chunk(const uint32_t *__restrict__ elems, uint4 *nodes, size_t n, uint32_t lvl_in, uint32_t chunk,
+                                              size_t first, uint32_t row_cols, size_t row_stride, uint32_t *buf) {
     const uint32_t tid = threadIdx.x;
-    const size_t first = (size_t)blockIdx.x * chunk;   // position of the chunk inside level lvl_in
     uint32_t d[8];
     for (uint32_t i = tid; i < chunk; i += SMI_TOP_THREADS) {
         if (FROM_ELEMS) {
@@ -209,12 +207,60 @@ __global__ __launch_bounds__(SMI_TOP_THREADS) void merkle_top_kernel(const uint3
         }
         __syncthreads();
     }
-    if (hook.fs_words && tid == 0 && gridDim.x == 1 && blockIdx.y == 0) {   // the root sits in slot `base` of every word row
+    return base;
+}
+
+template <bool FROM_ELEMS>
+__global__ __launch_bounds__(SMI_TOP_THREADS) void merkle_top_kernel(const uint32_t *__restrict__ elems, uint4 *nodes, size_t n,
+                                                                      uint32_t lvl_in, uint32_t chunk, size_t elem_stride,
+                                                                      size_t node_stride, uint32_t row_cols, size_t row_stride,
+                                                                      TopHook hook) {
+    __shared__ uint32_t buf[8 * SMI_TOP_MAX];
+    elems += (size_t)blockIdx.y * elem_stride;
+    nodes += (size_t)blockIdx.y * node_stride;
+    const uint32_t base = top_chunk<FROM_ELEMS>(elems, nodes, n, lvl_in, chunk, (size_t)blockIdx.x * chunk, row_cols, row_stride, buf);
+    if (hook.fs_words && threadIdx.x == 0 && gridDim.x == 1 && blockIdx.y == 0) {   // the root sits in slot `base` of every word row
         uint32_t m[8];
 #pragma unroll
         for (int w = 0; w < 8; w++) m[w] = buf[w * SMI_TOP_MAX + base];
         hashc::fs_absorb_root(hook.fs_words, m, hook.proof_slot, hook.alpha_out);
     }
+}
+
+// The tail of Fri::commit (reference src/fri.rs:116-148) in ONE launch: once a codeword has at most
+// SMI_TOP_MAX elements a single workgroup runs every remaining round -- leaf digests and the whole
+// tree (current level in LDS), the Fiat-Shamir round of its root by lane 0, the fold into the next
+// codeword -- with workgroup barriers where the host loop has kernel boundaries.  Trees, codewords,
+// root records and challenges land where the per-round kernels put them (the query phase reads them).
+__global__ __launch_bounds__(SMI_TOP_THREADS) void fri_tail_kernel(const FriTailArgs a) {
+    __shared__ uint32_t buf[8 * SMI_TOP_MAX];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t k = 0; k < a.n_rounds; k++) {
+        const FriTailRound R = a.r[k];
+        const uint32_t base = top_chunk<true>(R.cw, (uint4 *)R.nodes, R.len, 0, R.len, 0, 0, 0, buf);
+        if (tid == 0) {
+            uint32_t m[8];
+#pragma unroll
+            for (int w = 0; w < 8; w++) m[w] = buf[w * SMI_TOP_MAX + base];
+            hashc::fs_absorb_root(a.fs_words, m, R.proof_slot, R.alpha_out);   // no challenge after the last root
+            __threadfence_block();
+        }
+        __syncthreads();   // the challenge is in memory; buf may be overwritten by the next round
+        if (!R.next) break;
+        const uint32_t ah_m = fold_alpha_half(*(volatile const uint64_t *)R.alpha_out, a.inv2_m, a.F);
+        const uint32_t half = R.len >> 1;
+        for (uint32_t i = tid; i < half; i += SMI_TOP_THREADS) R.next[i] = fold_element(R.cw[i], R.cw[i + half], i, ah_m, a.inv2_m, R.S, a.F);
+        __threadfence_block();
+        __syncthreads();   // the next codeword is complete before its leaves are hashed
+    }
+}
+int launch_fri_tail(smi_ctx *ctx, const FriTailArgs &a) {
+    if (!a.n_rounds) return SMI_OK;
+    if (a.n_rounds > SMI_FRI_TAIL_MAX_ROUNDS || a.r[0].len > SMI_TOP_MAX) return smi_fail(ctx, SMI_ERR_BAD_ARG, "fri tail: too long");
+    ProfScope ps(ctx, "fri_tail_kernel", 0.0);
+    fri_tail_kernel<<<1, SMI_TOP_THREADS, 0, ctx->stream>>>(a);
+    HIP_TRY(ctx, hipGetLastError());
+    return SMI_OK;
 }
 
 // digests of rows of any width (the fused kernels above take rows of up to 4 columns)

@@ -67,6 +67,21 @@ struct ProfScope {
     }
 };
 
+// Every public entry point runs on the context's device whatever the caller's current device is
+// (a process may hold contexts on several GPUs, or torch may have selected another one), and
+// leaves the caller's selection as it found it.
+struct DeviceGuard {
+    int prev = -1;
+    bool moved = false;
+    explicit DeviceGuard(const smi_ctx *ctx) {
+        if (!ctx) return;
+        if (hipGetDevice(&prev) == hipSuccess && prev != ctx->device) moved = hipSetDevice(ctx->device) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (moved) (void)hipSetDevice(prev);
+    }
+};
+
 struct smi_tree {
     smi_ctx *ctx;
     uint8_t *d_nodes;   // (2n-1) x 32 bytes, level 0 first
@@ -103,6 +118,29 @@ inline uint32_t h_root(const smi_ctx *c, uint32_t log_n) {  // primitive 2^log_n
     return host_powmod(c->fs.wmax[0], 1ull << (c->fs.K - log_n), c->fs.F.p);
 }
 
+// One launch for the last rounds of Fri::commit (hash.hip, fri_tail_kernel): round k hashes and commits
+// cw (len elements), runs the Fiat-Shamir round of its root and, unless next == nullptr (the last
+// round), folds into next with the round's x^-1 table S.
+#define SMI_FRI_TAIL_MAX_ROUNDS 12
+#define SMI_FRI_TAIL_MAX_LEN 2048   // = SMI_TOP_MAX of hash.hip
+struct FriTailRound {
+    const uint32_t *cw;
+    uint32_t *next;
+    uint8_t *nodes;
+    uint8_t *proof_slot;
+    uint64_t *alpha_out;   // nullptr on the last round
+    ScaleTables S;
+    uint32_t len;
+};
+struct FriTailArgs {
+    FriTailRound r[SMI_FRI_TAIL_MAX_ROUNDS];
+    uint32_t n_rounds;
+    uint32_t *fs_words;
+    Fp F;
+    uint32_t inv2_m;
+};
+int launch_fri_tail(smi_ctx *ctx, const FriTailArgs &a);
+
 // launches (defined in the .hip files)
 int launch_geom_table(smi_ctx *ctx, const GeomSpec &s, uint32_t *d_out);
 int launch_narrow(smi_ctx *ctx, const uint64_t *d_in, uint32_t *d_out, size_t n, int reduce);
@@ -111,6 +149,8 @@ int dev_ntt(smi_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint32_t log_n,
             size_t in_stride, size_t out_stride, int inverse, uint64_t offset, uint64_t post_scale);
 int dev_lde2(smi_ctx *ctx, const uint32_t *d_coef, uint32_t *d_out, uint32_t log_n, uint32_t log_blowup, uint32_t batch,
              size_t coef_stride, size_t out_stride);
+int dev_ntt_shard_first(smi_ctx *ctx, uint32_t *d_strip, uint32_t log_n, uint32_t log_g, uint32_t rank, int inverse, uint64_t offset);
+int dev_ntt_shard_rest(smi_ctx *ctx, uint32_t *d_rows, uint32_t *d_out, uint32_t log_n, uint32_t log_g, int inverse);
 int check_flag(smi_ctx *ctx);  // syncs; SMI_ERR_NON_CANONICAL if a narrow kernel saw a value >= p
 // caller's (pageable) u64 buffers <-> device u32 residues; synchronous on return
 int host_to_dev_u32(smi_ctx *ctx, const uint64_t *host, size_t n, uint32_t *d_out, int reduce);

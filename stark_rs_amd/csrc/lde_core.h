@@ -58,7 +58,10 @@ struct LdeArgs {
 // A tile of pass B holds 16 lines = 2^rq cosets x 2^kq adjacent k1, rq = min(beta, 2)
 SMI_HD uint32_t lde_kq_bits(uint32_t beta) { return SMI_LDE_BLINES_LOG - (beta < 2 ? beta : 2u); }
 
-SMI_HD uint32_t lde_swz(uint32_t row) { return row ^ ((row >> 4) & 15u) ^ ((row >> 8) & 15u); }
+// It is linear over GF(2): for a base and an offset with no common bits, swz(base + offset) =
+// swz(base) ^ swz(offset), and the offsets below are compile-time constants after unrolling -- one XOR
+// per LDS access instead of the whole expression.
+SMI_HD constexpr uint32_t lde_swz(uint32_t row) { return row ^ ((row >> 4) & 15u) ^ ((row >> 8) & 15u); }
 
 // lde_coef_tile: coefficients [j1][j0] -> [j0 >> 2][j1][j0 & 3], as a transposition of the matrix of
 // 16-byte elements [R rows (j1)][256 columns (jt)].  One workgroup (256 threads) moves a 32 x 32 tile
@@ -115,7 +118,7 @@ template <int LOGR, int CAP> struct LdeA {
     }
     // rows pos + i*R/16 of column w: the inputs of the thread's radix-16 butterfly, times Omega^(r 2^10 j1)
     static SMI_HD void load_regs(const LdeArgs &a, const TileId &t, uint32_t batch, uint32_t (&v)[V], uint32_t tid) {
-        const uint32_t w = tid & 3u, pos = tid >> 2;
+        const uint32_t pos = tid >> 2;
         const uint32_t *col = a.coef_t + ((uint64_t)batch << a.L);
         const uint32_t o0 = (t.jt << (LOGR + 2)) + tid;       // [jt][j1 = pos + i R/16][w]: a wave reads 256 contiguous bytes
 #pragma unroll
@@ -133,7 +136,7 @@ template <int LOGR, int CAP> struct LdeA {
         }
     }
     static SMI_HD void step0(const LdeArgs &a, uint32_t (&x)[V], uint32_t *tile, const Tw2 *tw, uint32_t tid) {
-        const uint32_t w = tid & 3u, pos = tid >> 2;
+        const uint32_t w = tid & 3u, pos = tid >> 2, pos_sw = lde_swz(pos);
         int m[16];
 #pragma unroll
         for (int i = 0; i < 16; i++) m[i] = 1;
@@ -147,7 +150,7 @@ template <int LOGR, int CAP> struct LdeA {
             int mv = m[brev<4>(kk)];
             if (kk) v = shoup_mul(v, t0[kk], a.F.p);
             else lz_fold_to2(v, mv, a.F.p);
-            tile[lde_swz(pos + ((uint32_t)kk << (LOGR - 4))) * 4u + w] = v;
+            tile[((pos_sw ^ lde_swz((uint32_t)kk << (LOGR - 4))) << 2) + w] = v;   // row pos + kk R/16 (pos < R/16)
         }
     }
     static SMI_HD void step_mid(const LdeArgs &a, uint32_t *tile, const Tw2 *tw, uint32_t tid) {
@@ -157,12 +160,12 @@ template <int LOGR, int CAP> struct LdeA {
             const uint32_t u = tid + bi * NT;
             const uint32_t w = u & 3u, ub = u >> 2;
             const uint32_t blk = ub >> SUB, pos = ub & ((1u << SUB) - 1u);
-            const uint32_t base = (blk << MLOG) + pos;
+            const uint32_t base_sw = lde_swz((blk << MLOG) + pos);     // pos < 2^SUB: the q << SUB below share no bits with it
             uint32_t x[r];
             int m[r];
 #pragma unroll
             for (int q = 0; q < r; q++) {
-                x[q] = tile[lde_swz(base + ((uint32_t)q << SUB)) * 4u + w];
+                x[q] = tile[((base_sw ^ lde_swz((uint32_t)q << SUB)) << 2) + w];
                 m[q] = 2;
             }
             dft_regs<S, CAP>(x, m, tw, MLOG - S, a.F);
@@ -172,7 +175,7 @@ template <int LOGR, int CAP> struct LdeA {
                 int mv = m[brev<S>(kk)];
                 if (kk) v = shoup_mul(v, tw[(pos * kk) & (TWS - 1)], a.F.p);   // w_R^(16 pos kk)
                 else lz_fold_to2(v, mv, a.F.p);
-                tile[lde_swz(base + ((uint32_t)kk << SUB)) * 4u + w] = v;
+                tile[((base_sw ^ lde_swz((uint32_t)kk << SUB)) << 2) + w] = v;
             }
         }
     }
@@ -189,12 +192,12 @@ template <int LOGR, int CAP> struct LdeA {
         for (int bi = 0; bi < NB; bi++) {
             const uint32_t u = tid + bi * NT;
             const uint32_t w = u & 3u, d0 = (u >> 2) & 15u, d1 = u >> 6;
-            const uint32_t blk = (d0 << S1) | d1;
+            const uint32_t blk_sw = lde_swz(((d0 << S1) | d1) * RL);
             uint32_t x[RL];
             int m[RL];
 #pragma unroll
             for (int q = 0; q < RL; q++) {
-                x[q] = tile[lde_swz(blk * RL + q) * 4u + w];
+                x[q] = tile[((blk_sw ^ lde_swz((uint32_t)q)) << 2) + w];
                 m[q] = 2;
             }
             dft_regs<SL, CAP>(x, m, tw, LOGR - 4 - SL, a.F);
@@ -231,7 +234,8 @@ template <int LOGR> struct LdeAProbe {
         for (int bi = 0; bi < A::NB; bi++) {
             const uint32_t u = tid + bi * A::NT;
             const uint32_t w = u & 3u, d0 = (u >> 2) & 15u, d1 = u >> 6, k1b = d0 | (d1 << 4);
-            const uint32_t kq = lde_kq_bits(a.beta);
+            // tuning knob (SMI_LDE_DBG bits 16..23): store pieces of 2^(kq+4) bytes, kq = knob - 1 (0: the kernel's own)
+            const uint32_t knob = (a.dbg >> 16) & 255u, kq = knob ? knob - 1u : lde_kq_bits(a.beta);
             const uint32_t o0 = ((((k1b >> kq) << a.beta) + t.r) << (10 + kq)) + (t.jt << (kq + 2)) + ((k1b & ((1u << kq) - 1u)) << 2) + w;
 #pragma unroll
             for (int kk = 0; kk < A::RL; kk++) st32(mid, o0 + ((uint32_t)kk << (14 + St::s1 + a.beta)), v[bi * A::RL + kk] + 1u);
@@ -330,22 +334,51 @@ template <int CAP> struct LdeB {
 
 struct LdeBProbe {
     typedef LdeB<4> B;
+    // Tuning knob (SMI_LDE_DBG bits 8..15, copy-only runs): alternative access patterns of pass B, to
+    // price them without building the arithmetic around them.
+    //   0 the kernel's own pattern                 1 lines = 2 k1 x 8 cosets (64 contiguous bytes per output line)
+    //   2 lines = 8 k1 x 2 cosets                   3 both halves of every output line by ONE workgroup, one after the other
+    //   4 the kernel's pattern without xcd_tile     5 whole 128-byte output lines (half as many rows, 8 bytes per lane)
     static SMI_HD void run(const LdeArgs &a, uint32_t block, uint32_t batch, uint32_t tid) {
-        const B::TileId t = B::tile_id(a, block);
-        const B::Geo g = B::geo(a.beta);
-        uint32_t v[16];
-        B::load(a, t, batch, v, tid);
+        const uint32_t var = (a.dbg >> 8) & 255u;
+        B::Geo g = B::geo(a.beta);
+        if (var == 1 && a.beta >= 3) { g.rq_bits = 3; g.kq_bits = 1; g.rh_bits = a.beta - 3; }
+        if (var == 2) { g.rq_bits = 1; g.kq_bits = 3; g.rh_bits = a.beta - 1; }
+        const uint32_t *mid = a.mid + ((uint64_t)batch << (a.L + a.beta));
         uint32_t *out = a.out + (uint64_t)batch * a.out_stride;
         const uint32_t ksh = a.beta + a.L - SMI_LDE_LOGB;
-        const uint32_t base = ((t.k1_hi << g.kq_bits) << a.beta) + (t.rh << g.rq_bits);
+        const uint32_t reps = var == 3 ? 2u : 1u;
+        for (uint32_t rep = 0; rep < reps; rep++) {
+            uint32_t t = var == 4 ? block : xcd_tile(block, a.n_tiles);
+            if (var == 3) t = 2u * xcd_tile(block, a.n_tiles / 2u) + rep;     // launched with half as many workgroups
+            B::TileId id;
+            id.rh = t & ((1u << g.rh_bits) - 1u);
+            id.k1_hi = t >> g.rh_bits;
+            uint32_t v[16];
+            const uint32_t base_in = ((id.k1_hi << a.beta) + (id.rh << g.rq_bits)) << (10 + g.kq_bits);
 #pragma unroll
-        for (int bi = 0; bi < B::NB; bi++) {
-            const uint32_t u = tid + bi * B::NT;
-            const uint32_t l = u & (B::W - 1), blk = u >> SMI_LDE_BLINES_LOG;
-            const uint32_t lineoff = ((l & ((1u << g.kq_bits) - 1u)) << a.beta) + (l >> g.kq_bits);
-            const uint32_t o0 = (B::NP::blk_to_k(blk) << ksh) + base + lineoff;
+            for (int i = 0; i < 16; i++) v[i] = ld32(mid, base_in + (uint32_t)(i * B::NT) + tid);
+            const uint32_t base = ((id.k1_hi << g.kq_bits) << a.beta) + (id.rh << g.rq_bits);
+            if (var == 5) {   // lane pairs write 8 bytes each: 16 lanes cover one whole 128-byte line of one row
+                const uint32_t l = tid & 15u, row0 = tid >> 4;
+                const uint32_t line0 = ((id.k1_hi << g.kq_bits) << a.beta) & ~31u;
 #pragma unroll
-            for (int kk = 0; kk < B::RL; kk++) st32(out, o0 + ((uint32_t)kk << (SMI_LDE_LOGB - B::SL + ksh)), v[bi * B::RL + kk] + 1u);
+                for (int i = 0; i < 8; i++) {
+                    const uint32_t k0 = row0 + (uint32_t)i * 64u + ((id.rh & 1u) << 9);   // the partner tile takes the other 512 rows
+                    st32(out, (k0 << ksh) + line0 + 2u * l, v[2 * i] + 1u);
+                    st32(out, (k0 << ksh) + line0 + 2u * l + 1u, v[2 * i + 1] + 1u);
+                }
+                continue;
+            }
+#pragma unroll
+            for (int bi = 0; bi < B::NB; bi++) {
+                const uint32_t u = tid + bi * B::NT;
+                const uint32_t l = u & (B::W - 1), blk = u >> SMI_LDE_BLINES_LOG;
+                const uint32_t lineoff = ((l & ((1u << g.kq_bits) - 1u)) << a.beta) + (l >> g.kq_bits);
+                const uint32_t o0 = (B::NP::blk_to_k(blk) << ksh) + base + lineoff;
+#pragma unroll
+                for (int kk = 0; kk < B::RL; kk++) st32(out, o0 + ((uint32_t)kk << (SMI_LDE_LOGB - B::SL + ksh)), v[bi * B::RL + kk] + 1u);
+            }
         }
     }
 };

@@ -144,6 +144,12 @@ struct HipDev : MgDev {
             uint64_t offset, uint64_t post_scale) override {
         return dev_ntt(ctx, in, out, log_n, n_in, batch, in_stride, out_stride, inverse, offset, post_scale);
     }
+    int ntt_shard_first(uint32_t *strip, uint32_t log_n, uint32_t log_g, uint32_t rank, int inverse, uint64_t offset) override {
+        return dev_ntt_shard_first(ctx, strip, log_n, log_g, rank, inverse, offset);
+    }
+    int ntt_shard_rest(uint32_t *rows, uint32_t *out, uint32_t log_n, uint32_t log_g, int inverse) override {
+        return dev_ntt_shard_rest(ctx, rows, out, log_n, log_g, inverse);
+    }
     int interleave(const uint32_t *in, uint32_t *out, uint32_t n_cols, uint32_t log_b, size_t nq) override {
         if (log_b > 4) return fail(SMI_ERR_BAD_ARG, "mgpu: blowup above 16 is not sharded");
         if (!n_cols || !nq) return SMI_OK;
@@ -284,7 +290,7 @@ int smi_mgpu_create(smi_ctx *ctx, const uint8_t id[SMI_MGPU_ID_BYTES], int rank,
     if (!world_ok(rank, world)) return smi_fail(ctx, SMI_ERR_BAD_ARG, "mgpu: world size must be a power of two, 0 <= rank < world");
     RcclApi *api = rccl_api();
     if (!api) return smi_fail(ctx, SMI_ERR_RCCL, "librccl.so could not be loaded (set SMI_RCCL_LIB)");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dg__(ctx);
     RcclColl *coll = new RcclColl(ctx, api);
     ncclUniqueId u;
     memcpy(&u, id, sizeof u);
@@ -308,6 +314,7 @@ int smi_mgpu_create_with(smi_ctx *ctx, const smi_mgpu_coll *ops, int rank, int w
 
 void smi_mgpu_destroy(smi_mgpu *m) {
     if (!m) return;
+    DeviceGuard dg__(m->ctx);
     (void)hipStreamSynchronize(m->ctx->stream);
     delete m->coll;
     delete m;
@@ -330,7 +337,7 @@ static int give_proof(smi_ctx *ctx, const std::vector<uint8_t> &bytes, uint8_t *
 int smi_mgpu_fri_commit(smi_mgpu *m, const smi_fri_cfg *cfg, const uint32_t *d_block, size_t block_len, uint8_t *roots, uint64_t *alphas,
                         uint64_t *last_codeword, size_t *last_len) {
     if (!m || !cfg || !d_block) return SMI_ERR_BAD_ARG;
-    HIP_TRY(m->ctx, hipSetDevice(m->ctx->device));
+    DeviceGuard dg__(m->ctx);
     SMI_TRY(m->dev.reset());
     MgFriOut o;
     SMI_TRY(mg_fri_run(m->dev, *m->coll, m->rank, m->world, *cfg, d_block, block_len, m->min_block, false, o));
@@ -345,7 +352,7 @@ int smi_mgpu_fri_commit(smi_mgpu *m, const smi_fri_cfg *cfg, const uint32_t *d_b
 int smi_mgpu_fri_prove(smi_mgpu *m, const smi_fri_cfg *cfg, const uint32_t *d_block, size_t block_len, uint8_t **proof, size_t *proof_len,
                        uint64_t *top_indices) {
     if (!m || !cfg || !d_block || !proof || !proof_len) return SMI_ERR_BAD_ARG;
-    HIP_TRY(m->ctx, hipSetDevice(m->ctx->device));
+    DeviceGuard dg__(m->ctx);
     SMI_TRY(m->dev.reset());
     MgFriOut o;
     SMI_TRY(mg_fri_run(m->dev, *m->coll, m->rank, m->world, *cfg, d_block, block_len, m->min_block, true, o));
@@ -358,7 +365,7 @@ int smi_mgpu_lde(smi_mgpu *m, const uint32_t *d_trace_cols, uint32_t n_cols, uin
     if (!m || !d_trace_cols || !d_out_blocks || !n_cols) return SMI_ERR_BAD_ARG;
     if (log_n + log_blowup > m->ctx->fs.K)
         return smi_fail(m->ctx, m->ctx->fs.F.p == 998244353u ? SMI_ERR_ROOT_TOO_LARGE : SMI_ERR_UNSUPPORTED_PRIME, "LDE domain too large");
-    HIP_TRY(m->ctx, hipSetDevice(m->ctx->device));
+    DeviceGuard dg__(m->ctx);
     SMI_TRY(m->dev.reset());
     uint32_t *blocks = nullptr;
     SMI_TRY(mg_lde_blocks(m->dev, *m->coll, m->rank, m->world, d_trace_cols, n_cols, log_n, log_blowup, trace_offset, lde_offset, &blocks));
@@ -366,12 +373,26 @@ int smi_mgpu_lde(smi_mgpu *m, const uint32_t *d_trace_cols, uint32_t n_cols, uin
     return m->dev.copy(d_out_blocks, blocks, (size_t)n_cols * blk * 4);
 }
 
+int smi_mgpu_ntt(smi_mgpu *m, uint32_t *d_strip, uint32_t *d_out, uint32_t log_n, int inverse, uint64_t offset) {
+    if (!m || !d_strip || !d_out || d_strip == d_out) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(m->ctx);
+    SMI_TRY(m->dev.reset());
+    return mg_ntt(m->dev, *m->coll, m->rank, m->world, d_strip, d_out, log_n, inverse, offset);
+}
+int smi_mgpu_ntt_first_digit(uint32_t log_n, uint32_t *log_r0) {
+    if (!log_r0) return SMI_ERR_BAD_ARG;
+    const NttPlan pl = ntt_make_plan(log_n, 1);
+    if (pl.np < 2) return SMI_ERR_BAD_ARG;
+    *log_r0 = (uint32_t)pl.logr[0];
+    return SMI_OK;
+}
+
 int smi_mgpu_stark_prove(smi_mgpu *m, const smi_stark_cfg *cfg, const uint32_t *d_trace_cols, uint8_t *column_roots, uint8_t **proof,
                          size_t *proof_len, uint64_t *top_indices) {
     if (!m || !cfg || !d_trace_cols || !proof || !proof_len) return SMI_ERR_BAD_ARG;
     if (cfg->log_n + cfg->log_blowup > m->ctx->fs.K)
         return smi_fail(m->ctx, m->ctx->fs.F.p == 998244353u ? SMI_ERR_ROOT_TOO_LARGE : SMI_ERR_UNSUPPORTED_PRIME, "LDE domain too large");
-    HIP_TRY(m->ctx, hipSetDevice(m->ctx->device));
+    DeviceGuard dg__(m->ctx);
     MgStarkOut o;
     SMI_TRY(mg_stark_prove(m->dev, *m->coll, m->rank, m->world, *cfg, d_trace_cols, m->min_block, o));
     if (column_roots) memcpy(column_roots, o.column_roots.data(), o.column_roots.size());

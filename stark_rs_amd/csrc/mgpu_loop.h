@@ -31,6 +31,7 @@
 
 #include "../../include/stark_mi.h"
 #include "mgpu_core.h"
+#include "ntt_host.h"
 
 struct MgXfer {
     int peer;
@@ -87,6 +88,9 @@ struct MgDev {
                     uint32_t *out) = 0;
     virtual int ntt(const uint32_t *in, uint32_t *out, uint32_t log_n, size_t n_in, uint32_t batch, size_t in_stride, size_t out_stride,
                     int inverse, uint64_t offset, uint64_t post_scale) = 0;
+    // one transform sharded over 2^log_g ranks on the pass pipeline (ntt_driver.h)
+    virtual int ntt_shard_first(uint32_t *strip, uint32_t log_n, uint32_t log_g, uint32_t rank, int inverse, uint64_t offset) = 0;
+    virtual int ntt_shard_rest(uint32_t *rows, uint32_t *out, uint32_t log_n, uint32_t log_g, int inverse) = 0;
     // out[c][(q << log_b) + r] = in[(c << log_b) + r][q], q < nq, r < 2^log_b, c < n_cols
     virtual int interleave(const uint32_t *in, uint32_t *out, uint32_t n_cols, uint32_t log_b, size_t nq) = 0;
     virtual int combine(const uint32_t *cols, uint32_t n_cols, size_t len, size_t stride, const uint64_t *weights, uint32_t *out) = 0;
@@ -314,6 +318,44 @@ inline int mg_lde_blocks(MgDev &d, MgColl &coll, int rank, int G, const uint32_t
     MG_TRY(d.interleave(recv, blocks, W, log_b, nq));
     *blocks_out = blocks;
     return SMI_OK;
+}
+
+// ONE transform of 2^log_n points over the G ranks (SURVEY 8e "one large NTT", BASELINE configs[3]) on the
+// ordinary pass pipeline: with R_0 the plan's first digit and B = N / R_0,
+//   in : strip = this rank's columns [rank B/G, (rank+1) B/G) of the row-major [R_0][B] view of the input,
+//        as [R_0][B/G] (clobbered);
+//   1. pass 0 on the strip (its inter-pass twiddle w_N^(k_0 b) is the four-step twiddle);
+//   2. ONE all-to-all: rows k_0 in [h R_0/G, (h+1) R_0/G) of every strip go to rank h (each rank sends
+//      (G-1)/G of its N/G elements; point-to-point over xGMI), laid out as [R_0/G][B];
+//   3. the remaining passes, which are those of an (N/G)-point transform with first digit R_0/G;
+//   out: X[k_0 + R_0 * rest] at rest * (R_0/G) + (k_0 - rank R_0/G): natural-order runs of R_0/G outputs.
+// At G = 1 this is the direct transform, launch for launch.
+inline int mg_ntt(MgDev &d, MgColl &coll, int rank, int G, uint32_t *strip, uint32_t *out, uint32_t log_n, int inverse, uint64_t offset) {
+    using namespace mg;
+    if (G < 1 || !pow2((uint64_t)G) || rank < 0 || rank >= G) return d.fail(SMI_ERR_BAD_ARG, "mgpu: world size must be a power of two");
+    const uint32_t log_g = ilog2((uint64_t)G);
+    if (!ntt_shard_ok(log_n, log_g)) return d.fail(SMI_ERR_BAD_ARG, "mgpu: transform too small to shard over this many ranks");
+    const NttPlan pl = ntt_make_plan(log_n, 1);
+    const uint64_t n = 1ull << log_n, R0 = 1ull << pl.logr[0], B = n / R0;
+    const uint64_t rows = R0 / G, cols = B / G, blk = rows * cols;     // the block one rank sends to one rank
+    MG_TRY(d.ntt_shard_first(strip, log_n, log_g, (uint32_t)rank, inverse, offset));
+    uint32_t *mine = strip;
+    if (G > 1) {
+        uint32_t *stage = (uint32_t *)d.alloc((n / G) * 4), *rowsbuf = (uint32_t *)d.alloc((n / G) * 4);
+        if (!stage || !rowsbuf) return d.fail(SMI_ERR_OOM, "mgpu: transform buffers");
+        std::vector<MgXfer> sends, recvs;
+        for (int peer = 0; peer < G; peer++) {
+            if (peer == rank) continue;
+            sends.push_back(MgXfer{peer, strip + (uint64_t)peer * blk, blk * 4});
+            recvs.push_back(MgXfer{peer, stage + (uint64_t)peer * blk, blk * 4});
+        }
+        MG_TRY(pre(d, coll));
+        MG_TRY(coll.exchange(sends, recvs));
+        for (int g = 0; g < G; g++)      // [g][k_0][b_l] -> [k_0][g][b_l]
+            MG_TRY(d.copy_rows(rowsbuf + (uint64_t)g * cols, B * 4, (g == rank ? strip : stage) + (uint64_t)g * blk, cols * 4, cols * 4, rows));
+        mine = rowsbuf;
+    }
+    return d.ntt_shard_rest(mine, out, log_n, log_g, inverse);
 }
 
 struct MgStarkOut {

@@ -233,8 +233,8 @@ struct HipLauncher {
     void pass(int logr, int logw, bool last, const PassArgs &a, uint32_t batch) {
         // algorithmic bytes of one pass: every point read once and written once (4 B each);
         // the first pass of a zero-padded transform reads only its n_in real inputs
-        const double n = (double)(1ull << a.L);
-        const double bytes = ((a.flags & NTT_FIRST) ? 4.0 * a.n_in : 4.0 * n) * batch + 4.0 * n * batch;
+        const double n = (double)(1ull << (a.L - a.shard_log));   // points this launch moves (a strip of a sharded transform)
+        const double bytes = ((a.flags & NTT_FIRST) && !a.shard_log ? 4.0 * a.n_in : 4.0 * n) * batch + 4.0 * n * batch;
         const bool wide = a.F.p < (1u << 29);   // lazy range 8p instead of 4p (ntt_core.h)
         const int kind = last ? PASS_LAST : (a.flags & NTT_FIRST) ? PASS_FIRST : PASS_MID;
 #define X(LR, LW)                                                                                              \
@@ -298,7 +298,7 @@ int dev_lde2(smi_ctx *ctx, const uint32_t *d_coef, uint32_t *d_out, uint32_t log
         a.n_tiles = 1u << (logN - SMI_LDE_LOGB - SMI_LDE_BLINES_LOG);
         {
             ProfScope ps(ctx, "lde_copy_probe_b", 8.0 * N * batch);
-            lde_b_probe_kernel<<<dim3(a.n_tiles, batch), 1024, 0, ctx->stream>>>(a);
+            lde_b_probe_kernel<<<dim3(((a.dbg >> 8) & 255u) == 3 ? a.n_tiles / 2 : a.n_tiles, batch), 1024, 0, ctx->stream>>>(a);
         }
         HIP_TRY(ctx, hipGetLastError());
         return SMI_OK;
@@ -365,6 +365,48 @@ int dev_ntt(smi_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint32_t log_n,
     if (ntt_make_plan(log_n, batch).np > 0) SMI_TRY(ctx_scratch(ctx, (size_t)batch << log_n, &rq.scratch));   // inter-pass buffer
     HipLauncher ln{ctx};
     if (!ntt_run(ln, rq)) return smi_fail(ctx, SMI_ERR_BAD_ARG, "ntt: multi-pass plan without its inter-pass buffer");
+    if (ln.err != hipSuccess) return smi_hip_fail(ctx, ln.err, "ntt kernel launch");
+    return SMI_OK;
+}
+
+// One transform sharded over 2^log_g ranks on the pass pipeline (ntt_driver.h): pass 0 on this rank's
+// strip in place, and -- after the caller's exchange -- the remaining passes.
+static int shard_request(smi_ctx *ctx, uint32_t log_n, int inverse, uint64_t offset, NttRequest *rq) {
+    const uint32_t p = ctx->fs.F.p;
+    if (log_n > ctx->fs.K)
+        return smi_fail(ctx, p == 998244353u ? SMI_ERR_ROOT_TOO_LARGE : SMI_ERR_UNSUPPORTED_PRIME, "transform size exceeds the two-adicity of the modulus");
+    if (offset >= p) return smi_fail(ctx, SMI_ERR_NON_CANONICAL, "offset must be < p");
+    if (offset == 0) return smi_fail(ctx, SMI_ERR_NO_INVERSE, "offset must be invertible");
+    if (inverse && offset != 1) return smi_fail(ctx, SMI_ERR_BAD_ARG, "sharded inverse transform: offset must be 1");
+    memset(rq, 0, sizeof *rq);
+    rq->L = log_n; rq->n_in = (uint32_t)(1ull << log_n); rq->batch = 1; rq->F = ctx->fs.F;
+    rq->T = ctx_tables(ctx, inverse);
+    if (!inverse) {
+        rq->pre_scale = offset != 1;
+        rq->q_plain = (uint32_t)offset;
+        if (rq->pre_scale) SMI_TRY(ctx_scale_tables(ctx, 1, (uint32_t)offset, log_n, &rq->S));
+    } else {
+        rq->post_scale = true;   // n^-1, constant
+        rq->q_plain = 1;
+        SMI_TRY(ctx_scale_tables(ctx, h_inv(ctx, (uint32_t)((1ull << log_n) % p)), 1, log_n, &rq->S));
+    }
+    return SMI_OK;
+}
+int dev_ntt_shard_first(smi_ctx *ctx, uint32_t *d_strip, uint32_t log_n, uint32_t log_g, uint32_t rank, int inverse, uint64_t offset) {
+    NttRequest rq;
+    SMI_TRY(shard_request(ctx, log_n, inverse, offset, &rq));
+    rq.in = d_strip; rq.out = d_strip;
+    HipLauncher ln{ctx};
+    if (!ntt_run_shard_first(ln, rq, log_g, rank)) return smi_fail(ctx, SMI_ERR_BAD_ARG, "sharded transform: size too small for this many ranks");
+    if (ln.err != hipSuccess) return smi_hip_fail(ctx, ln.err, "ntt kernel launch");
+    return SMI_OK;
+}
+int dev_ntt_shard_rest(smi_ctx *ctx, uint32_t *d_rows, uint32_t *d_out, uint32_t log_n, uint32_t log_g, int inverse) {
+    NttRequest rq;
+    SMI_TRY(shard_request(ctx, log_n, inverse, 1, &rq));
+    rq.scratch = d_rows; rq.out = d_out;
+    HipLauncher ln{ctx};
+    if (!ntt_run_shard_rest(ln, rq, log_g)) return smi_fail(ctx, SMI_ERR_BAD_ARG, "sharded transform: size too small for this many ranks");
     if (ln.err != hipSuccess) return smi_hip_fail(ctx, ln.err, "ntt kernel launch");
     return SMI_OK;
 }

@@ -82,6 +82,10 @@ struct PassArgs {
     uint32_t post_ratio_m;  // q^((R/r_last) << Sp): step of the output scale between a thread's stores (Montgomery)
     uint32_t post_bi_ratio_m;  // q^(r_last << Sp): step of the output scale between a thread's butterflies
     uint32_t zlog;          // first pass: inputs with top digit >= 16 >> zlog are zero padding (0..4)
+    // One transform sharded over 2^shard_log ranks (first pass only, 0 otherwise): this rank holds the
+    // columns b in [b_off, b_off + B >> shard_log) of the pass's [R][B] view as a strip [R][B >> shard_log];
+    // addresses use the strip's row length, twiddles / scales / padding the global index.
+    uint32_t shard_log, b_off;
 };
 
 // digit structure of the in-tile transform; s0 = 4 everywhere, so the 16 values a thread loads in
@@ -225,11 +229,11 @@ template <int LOGR, int LOGW, int KIND, int CAP> struct NttPass {
         TileId t;
         const uint32_t tix = xcd_tile(block, a.n_tiles);
         if (!LAST) {
-            const uint32_t blog = a.L - a.Sp - LOGR;       // log2 B
-            const uint32_t tpa = 1u << (blog - LOGW);      // tiles per sub-problem
+            const uint32_t ablog = a.L - a.Sp - LOGR - a.shard_log;   // log2 of the row length in memory (B, or the strip's)
+            const uint32_t tpa = 1u << (ablog - LOGW);                // tiles per sub-problem
             const uint32_t sub = tix / tpa;
             t.b0 = (tix % tpa) << LOGW;
-            t.in_base = ((uint64_t)sub << (a.L - a.Sp)) + t.b0;
+            t.in_base = ((uint64_t)sub << (a.L - a.Sp - a.shard_log)) + t.b0;
             t.out_base = t.in_base;
         } else {
             // lines: k_0 = k0_0 + l (l < W) with the remaining digits a_rest fixed
@@ -264,23 +268,25 @@ template <int LOGR, int LOGW, int KIND, int CAP> struct NttPass {
     // exactly the inputs of its radix-16 butterfly (pos = j0), so step 0 runs on them directly.
     // Z: rows i >= 16 >> Z are zero padding and are neither loaded nor scaled.
     template <int Z> static SMI_HD void load_regs(const PassArgs &a, const TileId &t, uint32_t batch, uint32_t (&v)[V], uint32_t tid) {
-        const uint32_t blog = a.L - a.Sp - LOGR;
+        const uint32_t blog = a.L - a.Sp - LOGR, ablog = blog - a.shard_log;
         const uint32_t w = tid & (W - 1), j0 = tid >> LOGW;
-        const uint32_t o0 = (j0 << blog) + w;
+        const uint32_t o0 = (j0 << ablog) + w;              // address within the tile's rows
         if constexpr (FIRST) {
-            // zero padding: in_base == b0 in the first pass, so b0 + o is the natural index.
+            // zero padding: in_base == b0 in the first pass, so b_off + b0 + (j << blog) + w is the natural index.
             // Branch-free (clamped address + select) so the loads issue back to back.
             const uint32_t *col = a.in + (uint64_t)batch * a.in_stride;
+            const uint32_t n0 = a.b_off + t.b0 + (j0 << blog) + w;
 #pragma unroll
             for (int i = 0; i < V; i++) {
                 if (i >= (V >> Z)) { v[i] = 0u; continue; }
-                const uint32_t g = t.b0 + o0 + ((uint32_t)(i * (NT >> LOGW)) << blog);
-                const uint32_t x = ld32(col, g < a.n_in ? g : 0u);
+                const uint32_t g = n0 + ((uint32_t)(i * (NT >> LOGW)) << blog);
+                const uint32_t ga = t.b0 + o0 + ((uint32_t)(i * (NT >> LOGW)) << ablog);
+                const uint32_t x = ld32(col, g < a.n_in ? ga : 0u);
                 v[i] = g < a.n_in ? x : 0u;
             }
             if (a.flags & NTT_PRE_SCALE) {
                 // coset scale q^g: g advances by the constant T<<blog between a thread's loads
-                uint32_t sc = two_level(a.S.lo, a.S.hi, a.S.h, t.b0 + o0, a.F);
+                uint32_t sc = two_level(a.S.lo, a.S.hi, a.S.h, n0, a.F);
                 const uint32_t rq = a.pre_ratio_m * a.F.pinv;
 #pragma unroll
                 for (int i = 0; i < (V >> Z); i++) {
@@ -291,7 +297,7 @@ template <int LOGR, int LOGW, int KIND, int CAP> struct NttPass {
         } else {
             const uint32_t *in = a.in + (uint64_t)batch * a.in_stride + t.in_base;
 #pragma unroll
-            for (int i = 0; i < V; i++) v[i] = ld32(in, o0 + ((uint32_t)(i * (NT >> LOGW)) << blog));
+            for (int i = 0; i < V; i++) v[i] = ld32(in, o0 + ((uint32_t)(i * (NT >> LOGW)) << ablog));
         }
     }
 
@@ -386,7 +392,7 @@ template <int LOGR, int LOGW, int KIND, int CAP> struct NttPass {
         uint32_t base_run = 0, gs = 0, gq = 0, gbi = 0, gbq = 0;   // first pass: g^kbase, g^(R/RL), g^RL
         uint32_t sc_run = 0, rq = 0, rbq = 0;                        // last pass: scale(kn_base) and ratios
         if constexpr (!LAST) {
-            const uint32_t b = t.b0 + (tid & (W - 1)), sh = a.T.K - mlog;
+            const uint32_t b = a.b_off + t.b0 + (tid & (W - 1)), sh = a.T.K - mlog;
             base_run = two_level(a.T.lo, a.T.hi, a.T.h, (b * blk_to_k(tid >> LOGW)) << sh, a.F);
             gs = two_level(a.T.lo, a.T.hi, a.T.h, (b << KSTEP_LOG) << sh, a.F);
             gq = gs * a.F.pinv;
@@ -413,7 +419,7 @@ template <int LOGR, int LOGW, int KIND, int CAP> struct NttPass {
             dft_regs<SL, CAP>(x, m, tw, LOGR - SL, a.F);   // outputs < CAP*p: fine for any multiply below
             const uint32_t kbase = blk_to_k(blk);
             if constexpr (!LAST) {
-                const uint32_t blog = mlog - LOGR;
+                const uint32_t blog = mlog - LOGR - a.shard_log;   // row length in memory
                 const uint32_t o0 = (kbase << blog) + w;
                 {
                     // inter-pass twiddles w_m^(k*b) = g^k, g = w_m^b: running products over kk (and over

@@ -72,3 +72,66 @@ template <class Launcher> inline bool ntt_run(Launcher &ln, const NttRequest &rq
     }
     return true;
 }
+
+// ---- one transform of 2^L points sharded over 2^log_g ranks, on the same pass pipeline.
+// With the plan's first digit R_0 and B = 2^L / R_0: rank g holds the columns [g B/G, (g+1) B/G) of
+// the [R_0][B] view as a strip [R_0][B/G].  ntt_run_shard_first runs pass 0 on the strip in place (its
+// inter-pass twiddle w_N^(k_0 b) IS the four-step twiddle).  After the exchange -- rank h receives
+// rows k_0 in [h R_0/G, (h+1) R_0/G) of every strip and lays them out as [R_0/G][B] -- the remaining
+// passes are literally passes 1.. of an (N/G)-point transform whose first digit is R_0/G
+// (ntt_run_shard_rest): sub-problem sizes, twiddles and digit order are those of the global plan, and
+// the last pass leaves X[k_0 + R_0 * rest] at rest * (R_0/G) + (k_0 - h R_0/G): natural-order runs
+// of R_0/G outputs.  Forward transforms take any coset offset; inverse ones offset 1 (constant scale).
+template <class Launcher> inline bool ntt_run_shard_first(Launcher &ln, const NttRequest &rq, uint32_t log_g, uint32_t rank) {
+    if (!ntt_shard_ok(rq.L, log_g)) return false;
+    const NttPlan pl = ntt_make_plan(rq.L, 1);
+    const uint64_t n = 1ull << rq.L;
+    PassArgs a;
+    memset(&a, 0, sizeof a);
+    a.in = rq.in; a.out = rq.out;
+    a.in_stride = a.out_stride = n >> log_g;
+    a.F = rq.F; a.T = rq.T; a.S = rq.S;
+    a.L = rq.L; a.Sp = 0; a.n_in = (uint32_t)n;
+    a.flags = NTT_FIRST | (rq.pre_scale ? NTT_PRE_SCALE : 0);
+    a.d0_log = (uint32_t)pl.logr[0];
+    a.n_tiles = (uint32_t)((n >> log_g) >> (pl.logr[0] + pl.logw[0]));
+    a.batch = 1;
+    const uint32_t blog = rq.L - (uint32_t)pl.logr[0];
+    a.shard_log = log_g;
+    a.b_off = rank << (blog - log_g);
+    const uint64_t pre_step = (uint64_t)((1u << (pl.logr[0] + pl.logw[0] - 4)) >> pl.logw[0]) << blog;
+    const uint32_t pr = host_powmod(rq.q_plain, pre_step, rq.F.p);
+    a.pre_ratio_m = (uint32_t)(((uint64_t)pr << 32) % rq.F.p);
+    a.zlog = 0;
+    ln.pass(pl.logr[0], pl.logw[0], false, a, 1);
+    return true;
+}
+
+// in: [R_0/G][B] (modified), out: the rank's 2^(L - log_g) outputs in the layout above
+template <class Launcher> inline bool ntt_run_shard_rest(Launcher &ln, const NttRequest &rq, uint32_t log_g) {
+    if (!ntt_shard_ok(rq.L, log_g)) return false;
+    const NttPlan pl = ntt_make_plan(rq.L, 1);
+    const uint32_t Ll = rq.L - log_g;
+    const uint64_t nl = 1ull << Ll;
+    uint32_t consumed = (uint32_t)pl.logr[0] - log_g;
+    for (int p = 1; p < pl.np; p++) {
+        const bool last = p == pl.np - 1;
+        PassArgs a;
+        memset(&a, 0, sizeof a);
+        a.in = rq.scratch;
+        a.out = last ? rq.out : rq.scratch;
+        a.in_stride = a.out_stride = nl;
+        a.F = rq.F; a.T = rq.T; a.S = rq.S;
+        a.L = Ll; a.Sp = consumed; a.n_in = (uint32_t)nl;
+        a.flags = last && rq.post_scale ? NTT_POST_SCALE : 0;
+        a.d0_log = (uint32_t)pl.logr[0] - log_g;
+        a.n_mid = (uint32_t)(pl.np - 2);
+        for (int d = 0; d < pl.np - 2; d++) a.mid_log[d] = (uint32_t)pl.logr[1 + d];
+        a.n_tiles = (uint32_t)(nl >> (pl.logr[p] + pl.logw[p]));
+        a.batch = 1;
+        a.pre_ratio_m = a.post_ratio_m = a.post_bi_ratio_m = rq.F.r1;   // scale sequences of a sharded transform are constant (q = 1)
+        ln.pass(pl.logr[p], pl.logw[p], last, a, 1);
+        consumed += (uint32_t)pl.logr[p];
+    }
+    return true;
+}

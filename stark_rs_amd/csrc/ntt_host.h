@@ -99,6 +99,14 @@ inline NttPlan ntt_make_plan(uint32_t L, uint32_t batch = 1) {
     return pl;
 }
 
+// can one 2^L-point transform be sharded over 2^log_g ranks on the pass pipeline (ntt_driver.h)?
+inline bool ntt_shard_ok(uint32_t L, uint32_t log_g) {
+    const NttPlan pl = ntt_make_plan(L, 1);
+    if (pl.np < 2) return false;
+    const int blog = (int)L - pl.logr[0];
+    return blog - (int)log_g >= pl.logw[0] && pl.logr[0] - (int)log_g >= pl.logw[pl.np - 1] && pl.logr[0] >= (int)log_g;
+}
+
 // log2 of the radix of the last in-tile step for a digit of logr bits (Steps<logr> in ntt_core.h)
 inline int ntt_last_step_log(int logr) { return logr == 6 ? 2 : logr == 7 ? 3 : logr == 8 ? 4 : logr == 9 ? 2 : 3; }  // 10, 11 -> 3
 

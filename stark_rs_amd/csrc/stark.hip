@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void combine_columns_kernel(const uint32_t *__
 int smi_dev_combine_columns(smi_ctx *ctx, const uint32_t *d_cols, uint32_t n_cols, size_t len, size_t stride,
                             const uint64_t *d_weights, uint32_t *d_out) {
     if (!ctx || !d_cols || !d_weights || !d_out || !n_cols) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     if (n_cols > 64) return smi_fail(ctx, SMI_ERR_BAD_ARG, "combine: at most 64 columns per call");
     if (!len) return SMI_OK;
     size_t grid = (len + 255) / 256;
@@ -94,6 +95,7 @@ int smi_dev_combine_columns(smi_ctx *ctx, const uint32_t *d_cols, uint32_t n_col
 int smi_dev_stark_prove(smi_ctx *ctx, const smi_stark_cfg *cfg, const uint32_t *d_trace_cols, uint8_t *column_roots,
                         uint8_t **proof, size_t *proof_len, uint64_t *top_indices, double *stage_ms) {
     if (!ctx || !cfg || !d_trace_cols || !proof || !proof_len) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
     const uint32_t W = cfg->n_cols, log_N = cfg->log_n + cfg->log_blowup;
     if (!W || W > 64) return smi_fail(ctx, SMI_ERR_BAD_ARG, "stark_prove: 1..64 columns");
     if (cfg->log_blowup < 2) return smi_fail(ctx, SMI_ERR_EXPANSION_TOO_SMALL, nullptr);  // Fri::new, src/fri.rs:45
@@ -102,10 +104,17 @@ int smi_dev_stark_prove(smi_ctx *ctx, const smi_stark_cfg *cfg, const uint32_t *
     const size_t N = (size_t)1 << log_N;
     const uint32_t T = cfg->row_leaves ? 1u : W;   // trees (and roots entering the transcript)
     SMI_TRY(arena_reset(ctx));
-    hipEvent_t ev[5];
+    struct Events {   // destroyed on every return path
+        hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        ~Events() {
+            for (hipEvent_t e : ev)
+                if (e) (void)hipEventDestroy(e);
+        }
+    } evs;
+    hipEvent_t *ev = evs.ev;
     const bool timed = stage_ms != nullptr;
     if (timed)
-        for (auto &e : ev) HIP_TRY(ctx, hipEventCreate(&e));
+        for (int i = 0; i < 5; i++) HIP_TRY(ctx, hipEventCreate(&ev[i]));
     auto mark = [&](int i) { if (timed) (void)hipEventRecord(ev[i], ctx->stream); };
 
     uint32_t *d_lde = (uint32_t *)arena_alloc(ctx, (size_t)W * N * 4);
@@ -160,7 +169,6 @@ int smi_dev_stark_prove(smi_ctx *ctx, const smi_stark_cfg *cfg, const uint32_t *
             (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
             stage_ms[i] = ms;
         }
-        for (auto &e : ev) (void)hipEventDestroy(e);
     }
     *proof = (uint8_t *)malloc(bytes.size() ? bytes.size() : 1);
     if (!*proof) return smi_fail(ctx, SMI_ERR_OOM, "malloc proof");

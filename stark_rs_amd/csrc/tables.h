@@ -18,11 +18,34 @@ struct FieldSetup {
     uint32_t wmax[2];    // primitive 2^K-th root: [0] forward, [1] inverse (plain form)
 };
 
-// Returns false when p is unusable (even, >= 2^30 -- the lazy butterflies need 4p < 2^32 --,
+// Returns false when p is unusable (composite, even, >= 2^30 -- the lazy butterflies need 4p < 2^32 --,
 // two-adicity < 12, or g not of full 2-power order).
+// Deterministic Miller-Rabin for n < 2^32 (witnesses 2, 7, 61).
+inline bool is_prime_u32(uint32_t n) {
+    if (n < 2) return false;
+    for (uint32_t q : {2u, 3u, 5u, 7u, 11u, 13u}) {
+        if (n == q) return true;
+        if (n % q == 0) return false;
+    }
+    uint32_t d = n - 1, r = 0;
+    while (!(d & 1)) { d >>= 1; r++; }
+    for (uint32_t a : {2u, 7u, 61u}) {
+        uint32_t x = host_powmod(a % n, d, n);
+        if (x == 1 || x == n - 1 || a % n == 0) continue;
+        bool witness = true;
+        for (uint32_t i = 1; i < r && witness; i++) {
+            x = host_mulmod(x, x, n);
+            if (x == n - 1) witness = false;
+        }
+        if (witness) return false;
+    }
+    return true;
+}
+
 inline bool field_setup(uint64_t p64, uint64_t g64, FieldSetup *fs) {
     if (p64 < 3 || p64 >= (1ull << 30) || (p64 & 1) == 0 || g64 == 0 || g64 >= p64) return false;
     const uint32_t p = (uint32_t)p64, g = (uint32_t)g64;
+    if (!is_prime_u32(p)) return false;   // every inverse here is a Fermat power: the modulus must be prime
     uint32_t two_adicity = 0;
     while (((p - 1) >> two_adicity) % 2 == 0) two_adicity++;
     if (two_adicity < SMI_TILE_LOG) return false;

@@ -128,6 +128,8 @@ def _sig(L):
     L.smi_mgpu_fri_prove.argtypes = [vp, C.POINTER(FriCfg), vp, sz, C.POINTER(vp), C.POINTER(sz), vp]
     L.smi_mgpu_lde.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, vp]
     L.smi_mgpu_stark_prove.argtypes = [vp, C.POINTER(StarkCfg), vp, vp, C.POINTER(vp), C.POINTER(sz), vp]
+    L.smi_mgpu_ntt.argtypes = [vp, vp, vp, C.c_uint32, i32, C.c_uint64]
+    L.smi_mgpu_ntt_first_digit.argtypes = [C.c_uint32, C.POINTER(C.c_uint32)]
     L._mgpu_sig = True
 
 
@@ -146,17 +148,17 @@ class MultiGpu:
         _sig(self.L)
         h = vp()
         if host is not None:
-            check(self.L.smi_mgpu_create_with(engine.ctx, C.byref(host.ops), rank, world, C.byref(h)), engine.ctx)
+            check(self.L.smi_mgpu_create_with(engine.h, C.byref(host.ops), rank, world, C.byref(h)), engine.h)
         else:
             buf = (C.c_uint8 * 128)()
             if rank == 0:
-                check(self.L.smi_mgpu_unique_id(buf), engine.ctx)
+                check(self.L.smi_mgpu_unique_id(buf), engine.h)
             ident = carry(bytes(buf), rank) if world > 1 else bytes(buf)
             buf = (C.c_uint8 * 128).from_buffer_copy(ident)
-            check(self.L.smi_mgpu_create(engine.ctx, buf, rank, world, C.byref(h)), engine.ctx)
+            check(self.L.smi_mgpu_create(engine.h, buf, rank, world, C.byref(h)), engine.h)
         self.h = h
         if min_block is not None:
-            check(self.L.smi_mgpu_set_min_block(self.h, min_block), engine.ctx)
+            check(self.L.smi_mgpu_set_min_block(self.h, min_block), engine.h)
 
     def close(self):
         if self.h:
@@ -166,7 +168,7 @@ class MultiGpu:
     def _ck(self, st):
         if st and self.host is not None and self.host.errors:
             raise RuntimeError("collective shim: " + "; ".join(self.host.errors))
-        check(st, self.eng.ctx)
+        check(st, self.eng.h)
 
     def _take(self, proof, plen):
         out = C.string_at(proof, plen.value)
@@ -196,6 +198,15 @@ class MultiGpu:
     def lde(self, d_trace_cols, n_cols, log_n, log_blowup, d_out_blocks, trace_offset=1, lde_offset=None):
         lde_offset = self.eng.g if lde_offset is None else lde_offset
         self._ck(self.L.smi_mgpu_lde(self.h, d_trace_cols, n_cols, log_n, log_blowup, trace_offset, lde_offset, d_out_blocks))
+
+    def ntt_first_digit(self, log_n):
+        r0 = C.c_uint32()
+        check(self.L.smi_mgpu_ntt_first_digit(log_n, C.byref(r0)))
+        return r0.value
+
+    def ntt(self, d_strip, d_out, log_n, inverse=False, offset=1):
+        """one 2^log_n-point transform over the ranks (layouts: include/stark_mi.h, smi_mgpu_ntt)"""
+        self._ck(self.L.smi_mgpu_ntt(self.h, d_strip, d_out, log_n, 1 if inverse else 0, offset))
 
     def stark_prove(self, d_trace_cols, n_cols, log_n, log_blowup, num_colinearity_tests, trace_offset=1, lde_offset=None):
         """-> (column roots [W x bytes], proof bytes, top-level indices) on every rank"""

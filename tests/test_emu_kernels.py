@@ -211,3 +211,13 @@ def test_emulated_two_pass_lde_extremes_and_batch(emu, oracle):
         got = _lde2(emu, p, g, np.concatenate([a, b]), L, beta, batch=2).reshape(2, N)
         assert np.array_equal(got[0], o.fast_coset_ntt(a, N, W, 1, p))
         assert np.array_equal(got[1], o.fast_coset_ntt(b, N, W, 1, p))
+
+
+def test_field_setup_rejects_composite_moduli(emu):
+    """every inverse in the engine is a Fermat power, so field_setup (csrc/tables.h) must refuse an odd
+    composite with enough two-adicity (20481 = 3 * 6827 = 5 * 2^12 + 1) -- and still take both primes."""
+    x = np.arange(16, dtype=np.uint32)
+    out = np.zeros(16, dtype=np.uint32)
+    args = (x.ctypes.data_as(u32p), out.ctypes.data_as(u32p), 4, 16, 1, 16, 16, 0, 1, 1)
+    assert emu.emu_ntt(20481, 3, *args) == -1
+    assert emu.emu_ntt(P, G, *args) == 0 and emu.emu_ntt(P2, G2, *args) == 0

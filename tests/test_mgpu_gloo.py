@@ -32,6 +32,7 @@ def _emu():
                                        C.POINTER(sz), vp]
     L.emu_mgpu_lde.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(CollOps), i32, i32, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
                                C.c_uint64, u32p]
+    L.emu_mgpu_ntt.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(CollOps), i32, i32, u32p, u32p, C.c_uint32, i32, C.c_uint64]
     return L
 
 
@@ -112,6 +113,44 @@ def _stark_worker(rank, world, port, logn, lb, W, t, min_block, q):
     dist.destroy_process_group()
 
 
+def shard_strip(x, log_r0, rank, world):
+    """this rank's columns of the row-major [R_0][B] view of x, as [R_0][B/G]"""
+    R0 = 1 << log_r0
+    B = len(x) // R0
+    return np.ascontiguousarray(x.reshape(R0, B)[:, rank * B // world:(rank + 1) * B // world]).reshape(-1)
+
+
+def unshard_output(parts, log_r0, world):
+    """ranks' outputs ([N/R_0][R_0/G] each) -> natural order"""
+    R0 = 1 << log_r0
+    rest = len(parts[0]) * world // R0
+    return np.concatenate([p.reshape(rest, R0 // world) for p in parts], axis=1).reshape(-1)
+
+
+def _ntt_worker(rank, world, port, logn, inverse, offset, p, g, q):
+    L, coll = _init(rank, world, port)
+    import torch
+    from oracle import oracle as o
+    from stark_rs_amd._lib import lib
+    n = 1 << logn
+    x = (o.splitmix64(5 + logn, n) % np.uint64(p)).astype(np.uint32)
+    log_r0 = C.c_uint32()
+    # the plan's first digit is part of the data-layout contract: ask the product library's planner
+    import stark_rs_amd.mgpu as m
+    m._sig(lib())
+    assert lib().smi_mgpu_ntt_first_digit(logn, C.byref(log_r0)) == 0
+    strip = shard_strip(x, log_r0.value, rank, world).copy()
+    out = np.zeros(n // world, dtype=np.uint32)
+    rc = L.emu_mgpu_ntt(p, g, C.byref(coll.ops), rank, world, strip.ctypes.data_as(u32p), out.ctypes.data_as(u32p), logn, inverse, offset)
+    parts = [torch.zeros(n // world, dtype=torch.int32) for _ in range(world)]
+    dist.all_gather(parts, torch.from_numpy(out.view(np.int32)))
+    got = unshard_output([t.numpy().view(np.uint32) for t in parts], log_r0.value, world).astype(np.uint64)
+    w = o.ff_prim_nth_root_g(n, p, g)
+    want = o.fast_intt(x, w, 1, p) if inverse else o.fast_coset_ntt(x, n, w, offset, p)
+    q.put((rank, bool(rc == 0 and not coll.errors and np.array_equal(got, want)), rc, coll.errors))
+    dist.destroy_process_group()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -152,3 +191,15 @@ def test_native_loop_fri_prove_is_byte_identical_on_every_rank(oracle, world, lo
 ])
 def test_native_loop_stark_prove_equals_single_process_composition(oracle, world, logn, lb, W, t, min_block):
     _run(_stark_worker, world, (logn, lb, W, t, min_block))
+
+
+@pytest.mark.parametrize("world,logn,inverse,offset,p,g", [
+    (2, 16, 0, 1, P, G),              # two-pass plan (8, 8): pass 0 on strips, last pass after the exchange
+    (4, 21, 0, 3, 469762049, 3),      # three-pass plan, coset offset, second prime
+    (2, 17, 1, 1, P, G),              # inverse
+    (8, 21, 0, 7, P, G),              # BASELINE configs[3]'s world size
+])
+def test_native_loop_sharded_ntt_on_the_pass_pipeline(oracle, world, logn, inverse, offset, p, g):
+    """smi_mgpu_ntt's loop: pass 0 on column strips, ONE all-to-all, the remaining passes -- equals the
+    single transform (Polynomial::eval_domain / interpolate_domain on a geometric domain)."""
+    _run(_ntt_worker, world, (logn, inverse, offset, p, g))
