@@ -112,6 +112,7 @@ void smi_ctx_destroy(smi_ctx *ctx) {
         (void)hipFree(e.lo);
         (void)hipFree(e.hi);
     }
+    for (uint32_t *t : ctx->d_root_tab) (void)hipFree(t);
     (void)hipFree(ctx->scratch);
     (void)hipFree(ctx->arena);
     for (void *q : ctx->arena_overflow) (void)hipFree(q);
@@ -244,6 +245,24 @@ int ctx_scratch(smi_ctx *ctx, size_t elems, uint32_t **out) {
 NttTables ctx_tables(const smi_ctx *ctx, int inverse) {
     const int d = inverse ? 1 : 0;
     return NttTables{(const Tw2 *)ctx->d_tab[d][0], ctx->d_tab[d][1], ctx->d_tab[d][2], ctx->fs.K, ntt_table_h(ctx->fs.K)};
+}
+int ctx_root_table(smi_ctx *ctx, uint32_t log_m, const Tw2 **out) {
+    if (log_m > 17 || log_m > ctx->fs.K) return smi_fail(ctx, SMI_ERR_BAD_ARG, "root table too large");
+    if (!ctx->d_root_tab[log_m]) {
+        const Fp &F = ctx->fs.F;
+        const uint32_t w = h_root(ctx, log_m);
+        const GeomSpec sp{F.r1, (uint32_t)(((uint64_t)w << 32) % F.p), 1, 1u << log_m, 1};
+        uint32_t *d = nullptr;
+        if (hipMalloc((void **)&d, ((size_t)8) << log_m) != hipSuccess) return smi_fail(ctx, SMI_ERR_OOM, "hipMalloc root table");
+        const int rc = launch_geom_table(ctx, sp, d);
+        if (rc != SMI_OK) {
+            (void)hipFree(d);
+            return rc;
+        }
+        ctx->d_root_tab[log_m] = d;
+    }
+    *out = (const Tw2 *)ctx->d_root_tab[log_m];
+    return SMI_OK;
 }
 int ctx_scale_tables(smi_ctx *ctx, uint32_t c_plain, uint32_t q_plain, uint32_t L, ScaleTables *out) {
     for (const ScaleEntry &e : ctx->scale_cache)

@@ -204,7 +204,7 @@ template <int CAP> void emu_lde_b(const LdeArgs &a) {
                 B::load(a, t, b, v, tid);
                 B::to_lds(a, v, tile.data(), tid);
             }
-            for (uint32_t tid = 0; tid < B::NT; tid++) B::step0(a, tile.data(), tw.data(), tid);
+            for (uint32_t tid = 0; tid < B::NT; tid++) B::step0(a, t, tile.data(), tw.data(), tid);
             for (uint32_t tid = 0; tid < B::NT; tid++) B::step_mid(a, tile.data(), tw.data(), tid);
             for (uint32_t tid = 0; tid < B::NT; tid++) B::last_step_store(a, t, b, tile.data(), tw.data(), tid);
         }
@@ -219,9 +219,12 @@ extern "C" int emu_lde2(uint64_t p, uint64_t g, const uint32_t *coef, uint32_t *
     ntt_table_specs(fs, 0, sp);
     std::vector<uint32_t> tw10 = fill(sp[0], F), lo = fill(sp[1], F), hi = fill(sp[2], F);
     std::vector<uint32_t> mid((size_t)batch << (L + beta)), coef_t((size_t)batch << L);
+    const uint32_t log_m = L - SMI_LDE_LOGB + beta;
+    const uint32_t wm = host_powmod(fs.wmax[0], 1ull << (fs.K - log_m), F.p);
+    std::vector<uint32_t> ctab = fill(GeomSpec{F.r1, (uint32_t)(((uint64_t)wm << 32) % F.p), 1, 1u << log_m, 1}, F);
     LdeArgs a;
     memset(&a, 0, sizeof a);
-    a.coef = coef; a.mid = mid.data(); a.coef_t = coef_t.data(); a.out = out; a.coef_stride = 1ull << L; a.out_stride = 1ull << (L + beta);
+    a.coef = coef; a.mid = mid.data(); a.coef_t = coef_t.data(); a.ctab = (const Tw2 *)ctab.data(); a.out = out; a.coef_stride = 1ull << L; a.out_stride = 1ull << (L + beta);
     a.F = F; a.T = NttTables{(const Tw2 *)tw10.data(), lo.data(), hi.data(), fs.K, ntt_table_h(fs.K)};
     a.L = L; a.beta = beta; a.batch = batch;
     const bool wide = F.p < (1u << 29);

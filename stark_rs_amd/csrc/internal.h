@@ -27,6 +27,7 @@ struct smi_ctx {
     FieldSetup fs;
     uint32_t *d_tab[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};  // [dir][tw10, lo, hi]
     std::vector<ScaleEntry> scale_cache;
+    uint32_t *d_root_tab[32] = {};   // [log m]: w_m^e, e < m, as (value, Shoup quotient) pairs (ctx_root_table)
     uint32_t *scratch = nullptr;   // NTT inter-pass buffer
     size_t scratch_elems = 0;
     void *tmp[4] = {nullptr, nullptr, nullptr, nullptr};  // staging buffers of the host-buffer entry points
@@ -108,6 +109,8 @@ int ctx_tmp(smi_ctx *ctx, int slot, size_t bytes, void **out);
 int ctx_scratch(smi_ctx *ctx, size_t elems, uint32_t **out);
 NttTables ctx_tables(const smi_ctx *ctx, int inverse);
 // device tables of c * q^i, i < 2^L (cached per (c,q,L))
+// device table of w_m^e, e < m = 2^log_m (forward root), as Tw2 pairs; cached per log_m (log_m <= 17)
+int ctx_root_table(smi_ctx *ctx, uint32_t log_m, const Tw2 **out);
 int ctx_scale_tables(smi_ctx *ctx, uint32_t c_plain, uint32_t q_plain, uint32_t L, ScaleTables *out);
 
 // field helpers on the host (plain form)

@@ -45,6 +45,7 @@ struct LdeArgs {
     uint64_t coef_stride, out_stride;
     Fp F;
     NttTables T;            // forward direction
+    const Tw2 *ctab;        // w_M^e, e < M = 2^(L - 10 + beta), with Shoup quotients: Omega^(2^10 r j1) = ctab[(r j1) mod M]
     uint32_t L, beta;
     uint32_t n_tiles;       // grid.x of the launch this struct goes to
     uint32_t batch;         // grid.y
@@ -124,22 +125,20 @@ template <int LOGR, int CAP> struct LdeA {
 #pragma unroll
         for (int i = 0; i < V; i++) v[i] = ld32(col, o0 + (uint32_t)(i * (R / 4)));
         if (t.r) {
-            const uint32_t sh = a.T.K - LOGR - a.beta;      // Omega^(2^10) = W^(2^sh), W the table's 2^K-th root
-            uint32_t cur = two_level(a.T.lo, a.T.hi, a.T.h, (t.r * pos) << sh, a.F);
-            const uint32_t ratio = two_level(a.T.lo, a.T.hi, a.T.h, (t.r * (uint32_t)(R / 16)) << sh, a.F);
-            const uint32_t rq = ratio * a.F.pinv;
+            // the coset's input scale Omega^(r 2^10 j1) = w_M^(r j1): one table read and one Shoup product per
+            // input (a running product costs 13 instructions per input against these 4 + a load; the
+            // generic first pass pays 14 products per 16 outputs for its three degenerate stages)
+            const uint32_t mask = (1u << (LOGR + a.beta)) - 1u;
+            const uint32_t e0 = t.r * pos, es = t.r * (uint32_t)(R / 16);
 #pragma unroll
-            for (int i = 0; i < V; i++) {
-                v[i] = mont_mul(v[i], cur, a.F);
-                if (i + 1 < V) cur = mont_mul_c(cur, ratio, rq, a.F);
-            }
+            for (int i = 0; i < V; i++) v[i] = shoup_mul(v[i], ld_tw(a.ctab, (e0 + (uint32_t)i * es) & mask), a.F.p);   // [0, 2p)
         }
     }
     static SMI_HD void step0(const LdeArgs &a, uint32_t (&x)[V], uint32_t *tile, const Tw2 *tw, uint32_t tid) {
         const uint32_t w = tid & 3u, pos = tid >> 2, pos_sw = lde_swz(pos);
         int m[16];
 #pragma unroll
-        for (int i = 0; i < 16; i++) m[i] = 1;
+        for (int i = 0; i < 16; i++) m[i] = 2;      // scaled inputs are Shoup products in [0, 2p) (coset 0: canonical)
         Tw2 t0[16];
 #pragma unroll
         for (int kk = 1; kk < 16; kk++) t0[kk] = ld_tw(a.T.tw10, ((pos * kk) & (R - 1)) << (SMI_TW_LOG - LOGR));
@@ -187,7 +186,6 @@ template <int LOGR, int CAP> struct LdeA {
                                        uint32_t tid) {
         enum { S1 = St::s1, SL = St::s2 };
         uint32_t *mid = a.mid + ((uint64_t)batch << (a.L + a.beta));
-        const uint32_t logN = a.L + a.beta, sh = a.T.K - logN;
 #pragma unroll
         for (int bi = 0; bi < NB; bi++) {
             const uint32_t u = tid + bi * NT;
@@ -201,19 +199,16 @@ template <int LOGR, int CAP> struct LdeA {
                 m[q] = 2;
             }
             dft_regs<SL, CAP>(x, m, tw, LOGR - 4 - SL, a.F);
-            // Omega^(j0 * (r + 2^beta k1)), k1 = k1b + kk * 2^(4+S1): running product over kk
-            const uint32_t j0 = (t.jt << 2) + w, k1b = d0 | (d1 << 4);
-            uint32_t cur = two_level(a.T.lo, a.T.hi, a.T.h, (j0 * (t.r + (k1b << a.beta))) << sh, a.F);
-            const uint32_t gs = two_level(a.T.lo, a.T.hi, a.T.h, (j0 << (a.beta + 4 + S1)) << sh, a.F);
-            const uint32_t gq = gs * a.F.pinv;
+            // (the inter-pass twiddle Omega^(j0 (r + 2^beta k1)) is applied by pass B as it reads: B is bound by
+            // memory and has the issue slots, this pass is bound by arithmetic)
+            const uint32_t k1b = d0 | (d1 << 4);
             // [k1 >> kq][r][jt][k1 & (2^kq - 1)][w]; kk only moves k1 >> kq
             const uint32_t kq = lde_kq_bits(a.beta);
             const uint32_t o0 = ((((k1b >> kq) << a.beta) + t.r) << (10 + kq)) + (t.jt << (kq + 2)) + ((k1b & ((1u << kq) - 1u)) << 2) + w;
 #pragma unroll
             for (int kk = 0; kk < RL; kk++) {
-                const uint32_t val = mont_mul(x[brev<SL>(kk)], cur, a.F);
+                const uint32_t val = lz_canon_m(x[brev<SL>(kk)], m[brev<SL>(kk)], a.F.p);
                 if (!((a.dbg & 1u) && val != 0xFFFFFFFFu)) st32(mid, o0 + ((uint32_t)kk << (14 + S1 + a.beta)), val);
-                if (kk + 1 < RL) cur = mont_mul_c(cur, gs, gq, a.F);
             }
         }
     }
@@ -292,10 +287,33 @@ template <int CAP> struct LdeB {
             tile[((jt << 2) + j0lo) * WP + ((rq << g.kq_bits) | k1q)] = v[i];
         }
     }
-    static SMI_HD void step0(const LdeArgs &a, uint32_t *tile, const Tw2 *tw, uint32_t tid) {
-        PassArgs pa;
-        pa.F = a.F;
-        NP::step0_lds(pa, tile, tw, tid);
+    // First in-tile step (radix 16 over rows pos + 64 q of line l), with the inter-pass twiddle
+    // Omega^(j0 E), E = r + 2^beta k1 of the line, applied to the inputs as they come out of LDS: along a
+    // thread's 16 rows it is a geometric sequence, so one running product.
+    static SMI_HD void step0(const LdeArgs &a, const TileId &t, uint32_t *tile, const Tw2 *tw, uint32_t tid) {
+        const Geo g = geo(a.beta);
+        const uint32_t l = tid & (W - 1), pos = tid >> SMI_LDE_BLINES_LOG;          // pos < 64
+        const uint32_t r = (t.rh << g.rq_bits) | (l >> g.kq_bits), k1 = (t.k1_hi << g.kq_bits) | (l & ((1u << g.kq_bits) - 1u));
+        const uint32_t E = r + (k1 << a.beta), sh = a.T.K - (a.L + a.beta);
+        uint32_t cur = two_level(a.T.lo, a.T.hi, a.T.h, (pos * E) << sh, a.F);
+        const uint32_t ratio = two_level(a.T.lo, a.T.hi, a.T.h, (E << 6) << sh, a.F), rq = ratio * a.F.pinv;
+        uint32_t x[16];
+        int m[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            x[q] = mont_mul(tile[(pos + ((uint32_t)q << 6)) * WP + l], cur, a.F);
+            m[q] = 1;
+            if (q + 1 < 16) cur = mont_mul_c(cur, ratio, rq, a.F);
+        }
+        dft_regs<4, CAP>(x, m, tw, SMI_LDE_LOGB - 4, a.F);
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) {
+            uint32_t v = x[brev<4>(kk)];
+            int mv = m[brev<4>(kk)];
+            if (kk) v = shoup_mul(v, tw[(pos * kk) & (R - 1)], a.F.p);
+            else lz_fold_to2(v, mv, a.F.p);
+            tile[(pos + ((uint32_t)kk << 6)) * WP + l] = v;
+        }
     }
     static SMI_HD void step_mid(const LdeArgs &a, uint32_t *tile, const Tw2 *tw, uint32_t tid) {
         PassArgs pa;

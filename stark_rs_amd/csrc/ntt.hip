@@ -121,7 +121,7 @@ __global__ __launch_bounds__(1024) void lde_b_kernel(const LdeArgs a) {
     B::load(a, t, batch, v, tid);
     B::to_lds(a, v, tile, tid);
     __syncthreads();
-    B::step0(a, tile, tw, tid);
+    B::step0(a, t, tile, tw, tid);
     __syncthreads();
     B::step_mid(a, tile, tw, tid);
     __syncthreads();
@@ -274,6 +274,7 @@ int dev_lde2(smi_ctx *ctx, const uint32_t *d_coef, uint32_t *d_out, uint32_t log
     memset(&a, 0, sizeof a);
     a.coef = d_coef; a.out = d_out; a.coef_stride = coef_stride; a.out_stride = out_stride;
     a.F = ctx->fs.F; a.T = ctx_tables(ctx, 0); a.L = log_n; a.beta = log_blowup; a.batch = batch;
+    SMI_TRY(ctx_root_table(ctx, log_n - SMI_LDE_LOGB + log_blowup, &a.ctab));
     SMI_TRY(ctx_scratch(ctx, ((size_t)batch << logN) + ((size_t)batch << log_n), &a.mid));
     a.coef_t = a.mid + ((size_t)batch << logN);
     const bool wide = a.F.p < (1u << 29);
