@@ -273,6 +273,12 @@ typedef struct {
     uint32_t row_leaves;   /* 0: one tree per column, one element per leaf (the reference's leaf rule, src/fri.rs:118-121);
                               1: one tree over the rows (smi_dev_merkle_build_rows) -- a build-defined variant */
     uint64_t trace_offset, lde_offset, num_colinearity_tests;
+    uint64_t open_columns; /* 1: after the FRI objects, bind the combined codeword to the committed columns -- for every
+                              colinearity test s, with a = top_index[s] mod N/2 and b = a + N/2 (the layer-0 positions
+                              Fri::query opens, src/fri.rs:215-248): FieldElements([col_0[a] .. col_{W-1}[a]]),
+                              FieldElements([col_0[b] .. col_{W-1}[b]]) for s = 0 .. t-1, then MerklePath(col_c, a),
+                              MerklePath(col_c, b) for every s and, inside it, every c (tags and widths of src/stream.rs:35-64).  A verifier checks each path against
+                              column root c and sum_c weight_c * col_c[a] against the FRI triple's value.  Column trees only. */
 } smi_stark_cfg;
 int smi_dev_stark_prove(smi_ctx *ctx, const smi_stark_cfg *cfg, const uint32_t *d_trace_cols, uint8_t *column_roots,
                         uint8_t **proof, size_t *proof_len, uint64_t *top_indices, double *stage_ms);

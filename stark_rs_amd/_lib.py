@@ -34,7 +34,8 @@ class KernelTime(C.Structure):
 
 class StarkCfg(C.Structure):
     _fields_ = [("log_n", C.c_uint32), ("log_blowup", C.c_uint32), ("n_cols", C.c_uint32), ("row_leaves", C.c_uint32),
-                ("trace_offset", C.c_uint64), ("lde_offset", C.c_uint64), ("num_colinearity_tests", C.c_uint64)]
+                ("trace_offset", C.c_uint64), ("lde_offset", C.c_uint64), ("num_colinearity_tests", C.c_uint64),
+                ("open_columns", C.c_uint64)]
 
 
 class FriCfg(C.Structure):

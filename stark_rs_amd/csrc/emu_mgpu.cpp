@@ -169,6 +169,11 @@ struct EmuDev : MgDev {
             for (uint32_t s = 0; s < t; s++) mg_query_write(layers[l], top[s], s, rank, proof, 0, 1);
         return SMI_OK;
     }
+    int column_open(const MgSide *cols, uint32_t W, const uint64_t *top, uint32_t t, int rank, uint8_t *out) override {
+        for (uint32_t s = 0; s < t; s++)
+            for (uint32_t c = 0; c < W; c++) mg_column_open_write(cols, W, c, top[s], s, t, rank, out, 0, 1);
+        return SMI_OK;
+    }
     int lde(const uint32_t *trace, uint32_t n_cols, uint32_t log_n, uint32_t log_b, uint64_t trace_offset, uint64_t lde_offset,
             uint32_t *out) override {
         const uint64_t n = 1ull << log_n, N = n << log_b;

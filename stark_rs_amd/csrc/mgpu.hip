@@ -36,6 +36,7 @@ int launch_sample_indices(smi_ctx *ctx, const uint64_t *challenge, uint64_t size
                           uint64_t *indices, uint64_t *reduced);
 int launch_emit_codeword(smi_ctx *ctx, const uint32_t *cw, uint64_t len, uint8_t *dst);
 int launch_fs_weights(smi_ctx *ctx, const uint8_t *const *d_root_ptrs, uint32_t n, uint64_t *weights, uint8_t *roots_out);
+int launch_column_open(smi_ctx *ctx, const MgSide *d_cols, uint32_t W, const uint64_t *d_top, uint32_t t, int rank, uint8_t *d_out);
 
 // ------------------------------------------------------------------------- kernels
 // Fri::query for every (test, layer): each rank writes what it owns (mgpu_core.h)
@@ -135,6 +136,12 @@ struct HipDev : MgDev {
         mg_query_kernel<<<dim3(t, n_layers), 64, 0, ctx->stream>>>(d_layers, top, rank, proof);
         HIP_TRY(ctx, hipGetLastError());
         return SMI_OK;
+    }
+    int column_open(const MgSide *cols_host, uint32_t W, const uint64_t *top, uint32_t t, int rank, uint8_t *out) override {
+        MgSide *d_cols = (MgSide *)alloc(sizeof(MgSide) * W);
+        if (!d_cols) return fail(SMI_ERR_OOM, "mgpu: column table");
+        HIP_TRY(ctx, hipMemcpyAsync(d_cols, cols_host, sizeof(MgSide) * W, hipMemcpyHostToDevice, ctx->stream));
+        return launch_column_open(ctx, d_cols, W, top, t, rank, out);
     }
     int lde(const uint32_t *trace, uint32_t n_cols, uint32_t log_n, uint32_t log_b, uint64_t trace_offset, uint64_t lde_offset,
             uint32_t *out) override {

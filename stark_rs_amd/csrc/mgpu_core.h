@@ -84,3 +84,27 @@ SMI_HD void mg_query_write(const MgLayer &L, uint64_t top_index, uint32_t s, int
     mg_open_write(L.cur, c + half, rank, tr + 17, pp + pa, lane, n_lanes);
     mg_open_write(L.next, c, rank, tr + 25, pp + 2 * pa, lane, n_lanes);
 }
+
+// Column openings of the build-defined composition (smi_stark_cfg.open_columns): what ties the codeword FRI
+// proves low-degree to the W committed columns.  For test s: a = top mod N/2, b = a + N/2;
+//   rows : t x 2 records  tag 2 | u64 W | W x u64            (row a, then row b)
+//   paths: t x W x 2 records  tag 3 | u64 depth | depth x 32  (column c at a, then at b)
+// written like the FRI openings: values and digests by the rank that owns the leaf, tags by rank 0.
+SMI_HD uint64_t mg_column_open_bytes(uint32_t W, uint32_t t, uint32_t depth) {
+    return (uint64_t)t * 2 * (9 + 8ull * W) + (uint64_t)t * W * 2 * (9 + 32ull * depth);
+}
+SMI_HD void mg_column_open_write(const MgSide *cols, uint32_t W, uint32_t c, uint64_t top_index, uint32_t s, uint32_t t, int rank,
+                                 uint8_t *out, uint32_t lane, uint32_t n_lanes) {
+    const MgSide &side = cols[c];
+    const uint32_t depth = side.depth_local + side.depth_top;
+    const uint64_t half = side.len / 2, a = top_index % half, rec = 9 + 8ull * W, prec = 9 + 32ull * depth;
+    uint8_t *rows = out + (uint64_t)s * 2 * rec;
+    uint8_t *paths = out + (uint64_t)t * 2 * rec + ((uint64_t)s * W + c) * 2 * prec;
+    if (rank == 0 && c == 0 && lane == 0)
+        for (int k = 0; k < 2; k++) {
+            rows[k * rec] = 2;
+            mg_put_u64(rows + k * rec + 1, W);
+        }
+    mg_open_write(side, a, rank, rows + 9 + 8ull * c, paths, lane, n_lanes);
+    mg_open_write(side, a + half, rank, rows + rec + 9 + 8ull * c, paths + prec, lane, n_lanes);
+}

@@ -83,6 +83,7 @@ struct MgDev {
     virtual int sample_indices(const uint64_t *challenge, uint64_t size, uint64_t reduced_size, uint32_t number, uint64_t *indices,
                                uint64_t *reduced) = 0;
     virtual int query(const MgLayer *layers_host, uint32_t n_layers, const uint64_t *top, uint32_t t, int rank, uint8_t *proof) = 0;
+    virtual int column_open(const MgSide *cols_host, uint32_t W, const uint64_t *top, uint32_t t, int rank, uint8_t *out) = 0;
     // extension: lde = all columns whole (interpolate on trace_offset <w_n>, evaluate on lde_offset <w_N>)
     virtual int lde(const uint32_t *trace, uint32_t n_cols, uint32_t log_n, uint32_t log_b, uint64_t trace_offset, uint64_t lde_offset,
                     uint32_t *out) = 0;
@@ -417,6 +418,31 @@ inline int mg_stark_prove(MgDev &d, MgColl &coll, int rank, int G, const smi_sta
     fc.expansion_factor = 1ull << cfg.log_blowup;
     fc.num_colinearity_tests = cfg.num_colinearity_tests;
     MG_TRY(mg_fri_run(d, coll, rank, G, fc, cw, blk, min_block, true, out.fri));
+    if (cfg.open_columns && cfg.num_colinearity_tests) {   // bind the codeword to the columns (mgpu_core.h)
+        const uint32_t t = (uint32_t)cfg.num_colinearity_tests;
+        std::vector<MgSide> sides(W);
+        for (uint32_t c = 0; c < W; c++) {
+            MgSide &sd = sides[c];
+            sd.cw = ext + (size_t)c * col_stride; sd.nodes = trees + c * tree_stride; sd.len = N; sd.blk = blk;
+            sd.depth_local = ilog2(blk);
+            sd.top = G == 1 ? nullptr : rootp[c] - (2 * (size_t)G - 2) * 32;
+            sd.depth_top = G == 1 ? 0 : ilog2((uint64_t)G);
+        }
+        const size_t ob = (size_t)mg_column_open_bytes(W, t, logN);
+        uint64_t *d_top = (uint64_t *)d.alloc(8 * (size_t)t);
+        uint8_t *d_open = (uint8_t *)d.alloc(ob);
+        if (!d_top || !d_open) return d.fail(SMI_ERR_OOM, "mgpu: column openings");
+        MG_TRY(d.upload(d_top, out.fri.top.data(), 8 * (size_t)t));
+        MG_TRY(d.zero(d_open, ob));
+        MG_TRY(d.column_open(sides.data(), W, d_top, t, rank, d_open));
+        if (G > 1) {
+            MG_TRY(pre(d, coll));
+            MG_TRY(coll.all_reduce_sum_u8(d_open, ob));
+        }
+        const size_t at = out.fri.proof.size();
+        out.fri.proof.resize(at + ob);
+        MG_TRY(d.download(out.fri.proof.data() + at, d_open, ob));
+    }
     out.column_roots.resize(32 * (size_t)W);
     return d.download(out.column_roots.data(), d_roots, 32 * (size_t)W);
 }

@@ -16,6 +16,7 @@
 
 #include "hash_core.h"
 #include "internal.h"
+#include "mgpu_core.h"
 
 int launch_merkle_batch(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_nodes, uint32_t n_trees, size_t elem_stride,
                         size_t node_stride_bytes, uint32_t row_cols = 0, size_t row_stride = 0);
@@ -40,6 +41,17 @@ __global__ void fs_weights_kernel(const uint8_t *const *root_ptrs, uint32_t n, u
         hashc::to_words(ch, d);
         weights[c] = (uint64_t)d[0] | ((uint64_t)d[1] << 32);
     }
+}
+
+// column openings (mgpu_core.h): one workgroup per (test, column)
+__global__ __launch_bounds__(64) void column_open_kernel(const MgSide *cols, uint32_t W, const uint64_t *top, uint32_t t, int rank, uint8_t *out) {
+    mg_column_open_write(cols, W, blockIdx.y, top[blockIdx.x], blockIdx.x, t, rank, out, threadIdx.x, 64);
+}
+int launch_column_open(smi_ctx *ctx, const MgSide *d_cols, uint32_t W, const uint64_t *d_top, uint32_t t, int rank, uint8_t *d_out) {
+    if (!W || !t) return SMI_OK;
+    column_open_kernel<<<dim3(t, W), 64, 0, ctx->stream>>>(d_cols, W, d_top, t, rank, d_out);
+    HIP_TRY(ctx, hipGetLastError());
+    return SMI_OK;
 }
 
 int launch_fs_weights(smi_ctx *ctx, const uint8_t *const *d_root_ptrs, uint32_t n, uint64_t *weights, uint8_t *roots_out) {
@@ -158,6 +170,30 @@ int smi_dev_stark_prove(smi_ctx *ctx, const smi_stark_cfg *cfg, const uint32_t *
     std::vector<uint8_t> bytes;
     SMI_TRY(fri_run(ctx, &fc, d_cw, N, true, false, nullptr, &bytes, top_indices, nullptr, nullptr, nullptr, nullptr));
     mark(4);
+    if (cfg->open_columns && !cfg->row_leaves && cfg->num_colinearity_tests) {
+        // the top-level indices are on the host now (fri_run synchronised): one more small launch
+        const uint32_t t = (uint32_t)cfg->num_colinearity_tests;
+        std::vector<uint64_t> top_tmp(t);
+        if (!top_indices) return smi_fail(ctx, SMI_ERR_BAD_ARG, "open_columns needs top_indices");
+        std::vector<MgSide> sides(W);
+        for (uint32_t c = 0; c < W; c++) {
+            MgSide &sd = sides[c];
+            sd.cw = d_lde + (size_t)c * N; sd.nodes = trees[c]; sd.top = nullptr; sd.len = N; sd.blk = N; sd.depth_local = log_N; sd.depth_top = 0;
+        }
+        const size_t ob = (size_t)mg_column_open_bytes(W, t, log_N);
+        MgSide *d_sides = (MgSide *)arena_alloc(ctx, sizeof(MgSide) * W);
+        uint64_t *d_top2 = (uint64_t *)arena_alloc(ctx, 8 * (size_t)t);
+        uint8_t *d_open = (uint8_t *)arena_alloc(ctx, ob);
+        if (!d_sides || !d_top2 || !d_open) return smi_fail(ctx, SMI_ERR_OOM, "stark_prove: column openings");
+        HIP_TRY(ctx, hipMemcpyAsync(d_sides, sides.data(), sizeof(MgSide) * W, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_top2, top_indices, 8 * (size_t)t, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(d_open, 0, ob, ctx->stream));
+        SMI_TRY(launch_column_open(ctx, d_sides, W, d_top2, t, 0, d_open));
+        const size_t at = bytes.size();
+        bytes.resize(at + ob);
+        HIP_TRY(ctx, hipMemcpyAsync(bytes.data() + at, d_open, ob, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     if (column_roots) {   // fri_run has synchronised; the arena (and d_roots) is intact until the next reset
         HIP_TRY(ctx, hipMemcpyAsync(column_roots, d_roots, 32 * (size_t)T, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

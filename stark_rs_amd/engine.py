@@ -333,11 +333,11 @@ class Engine:
         self._ck(self.L.smi_dev_combine_columns(self.h, vp(d_cols), n_cols, length, stride, vp(d_weights), vp(d_out)))
 
     def dev_stark_prove(self, d_trace_cols, n_cols, log_n, log_blowup, num_colinearity_tests, trace_offset=1,
-                        lde_offset=None, timed=False, row_leaves=False):
+                        lde_offset=None, timed=False, row_leaves=False, open_columns=False):
         """Build-defined prove.  -> dict(column_roots, proof, top_indices[, stage_ms]).
         row_leaves: commit to the extended trace with one tree over its rows instead of one per column."""
         cfg = _lib.StarkCfg(log_n, log_blowup, n_cols, 1 if row_leaves else 0, trace_offset,
-                            self.g if lde_offset is None else lde_offset, num_colinearity_tests)
+                            self.g if lde_offset is None else lde_offset, num_colinearity_tests, 1 if open_columns else 0)
         roots = np.zeros((1 if row_leaves else n_cols, 32), dtype=np.uint8)
         proof, plen = vp(), C.c_size_t()
         top = np.zeros(max(num_colinearity_tests, 1), dtype=np.uint64)

@@ -208,10 +208,11 @@ class MultiGpu:
         """one 2^log_n-point transform over the ranks (layouts: include/stark_mi.h, smi_mgpu_ntt)"""
         self._ck(self.L.smi_mgpu_ntt(self.h, d_strip, d_out, log_n, 1 if inverse else 0, offset))
 
-    def stark_prove(self, d_trace_cols, n_cols, log_n, log_blowup, num_colinearity_tests, trace_offset=1, lde_offset=None):
+    def stark_prove(self, d_trace_cols, n_cols, log_n, log_blowup, num_colinearity_tests, trace_offset=1, lde_offset=None,
+                    open_columns=False):
         """-> (column roots [W x bytes], proof bytes, top-level indices) on every rank"""
         lde_offset = self.eng.g if lde_offset is None else lde_offset
-        cfg = StarkCfg(log_n, log_blowup, n_cols, 0, trace_offset, lde_offset, num_colinearity_tests)
+        cfg = StarkCfg(log_n, log_blowup, n_cols, 0, trace_offset, lde_offset, num_colinearity_tests, 1 if open_columns else 0)
         roots = (C.c_uint8 * (32 * n_cols))()
         proof, plen = vp(), sz()
         top = (C.c_uint64 * max(num_colinearity_tests, 1))()

@@ -646,3 +646,57 @@ class Trace:
         rows = b"".join(int(v & ((1 << 128) - 1)).to_bytes(16, "little") for r in self.trace for v in r)
         cols = eng.trace_pack(rows, len(self.trace), self.num_columns)
         return eng.lde(cols, log_blowup, 1, lde_offset)
+
+
+def verify_column_openings(eng, proof: bytes, n_cols, log_n, log_blowup, num_colinearity_tests, column_roots, top_indices):
+    """Verifier side of smi_stark_cfg.open_columns (build-defined composition, include/stark_mi.h): the bytes
+    after the FRI objects must (1) open every committed column at the layer-0 positions a, b of every
+    colinearity test with authentication paths that verify against that column's root (MerkleTree::verify,
+    reference src/merkle.rs:82-96, in one device batch per column), and (2) combine, with the Fiat-Shamir
+    weights drawn from the column roots (fresh transcript: absorb root c, challenge -- src/fiat_shamir.rs:15-25),
+    to the values a and b of the FRI proof's layer-0 triples (src/fri.rs:229-236).  -> bool"""
+    p, W, t = eng.p, n_cols, num_colinearity_tests
+    N = 1 << (log_n + log_blowup)
+    depth, half = log_n + log_blowup, N // 2
+    rec, prec = 9 + 8 * W, 9 + 32 * depth
+    tail = t * 2 * rec + t * W * 2 * prec
+    if len(proof) < tail:
+        return False
+    fri, ext = proof[:len(proof) - tail], proof[len(proof) - tail:]
+    objs = ProofStream.deserialize(fri, FiniteField(p)).objects
+    rounds = sum(1 for o in objs if o.tag == 0)
+    triples = [o for o in objs if o.tag == 2][1:1 + t]            # after the last codeword: layer 0's t triples
+    if len(triples) != t:
+        return False
+    fs, weights = FiatShamir(), []
+    for root in column_roots:
+        fs.absorb(bytes(root))
+        weights.append(fs.challenge(FiniteField(p)).value % p)
+    rows = np.zeros((t, 2, W), dtype=np.uint64)
+    for s in range(t):
+        for k in range(2):
+            r = ext[(2 * s + k) * rec:(2 * s + k + 1) * rec]
+            if r[0] != 2 or int.from_bytes(r[1:9], "little") != W:
+                return False
+            rows[s, k] = np.frombuffer(r[9:], dtype="<u8")
+    base = t * 2 * rec
+    for c in range(W):
+        leaves, idx, paths = [], [], []
+        for s in range(t):
+            a = top_indices[s] % half
+            for k, i in enumerate((a, a + half)):
+                rp = ext[base + ((s * W + c) * 2 + k) * prec:base + ((s * W + c) * 2 + k + 1) * prec]
+                if rp[0] != 3 or int.from_bytes(rp[1:9], "little") != depth:
+                    return False
+                leaves.append(int(rows[s, k, c]))
+                idx.append(i)
+                paths.append(rp[9:])
+        digests = eng.hash_leaves(np.array(leaves, dtype=np.uint64))
+        if not eng.merkle_verify_batch(digests, idx, np.frombuffer(b"".join(paths), dtype=np.uint8), column_roots[c]).all():
+            return False
+    for s in range(t):
+        for k in range(2):
+            acc = sum(weights[c] * int(rows[s, k, c]) for c in range(W)) % p
+            if acc != triples[s].payload[k].value % p:
+                return False
+    return rounds > 0

@@ -324,3 +324,31 @@ def test_two_pass_lde_equals_oracle(eng, eng2, oracle, which, logn, lb, W):
         assert np.array_equal(got[c], o.fast_coset_ntt(o.fast_intt(cols[c], w, 1, p), N, Wn, g, p)), c
     e.dev_free(d_in)
     e.dev_free(d_out)
+
+
+@pytest.mark.parametrize("which", ["ref_prime", "second_prime"])
+def test_stark_prove_column_openings(eng, eng2, oracle, which):
+    """smi_stark_cfg.open_columns: the FRI proof bytes are unchanged, the appended openings are byte for byte
+    the oracle's restatement (tests/conftest.py), the host mirror's verifier accepts them, and tampering with
+    a column value or swapping a root is rejected."""
+    from conftest import column_openings_bytes
+    from stark_rs_amd.mirror import verify_column_openings
+    o = oracle
+    e, p, g = (eng, P, G) if which == "ref_prime" else (eng2, P2, G2)
+    logn, lb, W, t = 10, 3, 4, 8
+    n, N = 1 << logn, 1 << (logn + lb)
+    cols = np.stack([_vals(o, 0x5354524B00 + c, n, p) for c in range(W)])
+    d = _upload(e, cols)
+    plain = e.dev_stark_prove(d, W, logn, lb, t)
+    res = e.dev_stark_prove(d, W, logn, lb, t, open_columns=True)
+    e.dev_free(d)
+    assert res["proof"][:len(plain["proof"])] == plain["proof"] and res["top_indices"] == plain["top_indices"]
+    w, Wn = o.ff_prim_nth_root_g(n, p, g), o.ff_prim_nth_root_g(N, p, g)
+    lde = [o.fast_coset_ntt(o.fast_intt(cols[c], w, 1, p), N, Wn, g, p) for c in range(W)]
+    assert res["proof"][len(plain["proof"]):] == column_openings_bytes(o, lde, res["top_indices"], N)
+    roots = [bytes(r) for r in res["column_roots"]]
+    assert verify_column_openings(e, res["proof"], W, logn, lb, t, roots, res["top_indices"])
+    bad = bytearray(res["proof"])
+    bad[len(plain["proof"]) + 9] ^= 1                                  # col_0[a] of test 0
+    assert not verify_column_openings(e, bytes(bad), W, logn, lb, t, roots, res["top_indices"])
+    assert not verify_column_openings(e, res["proof"], W, logn, lb, t, roots[1:] + roots[:1], res["top_indices"])

@@ -79,7 +79,7 @@ def _stark_worker(rank, world, port, logn, lb, W, t, min_block, q):
     w, Wn = o.ff_prim_nth_root(n), o.ff_prim_nth_root(N)
     cols = np.stack([o.splitmix64(0x5354524B00 + c, n) % np.uint64(P) for c in range(W)])
     trace = np.ascontiguousarray(cols.reshape(-1).astype(np.uint32))
-    cfg = StarkCfg(logn, lb, W, 0, 1, G, t)
+    cfg = StarkCfg(logn, lb, W, 0, 1, G, t, 1)        # with the column openings appended after the FRI objects
     roots = (C.c_uint8 * (32 * W))()
     proof = (C.c_uint8 * (1 << 22))()
     plen = C.c_size_t()
@@ -108,6 +108,8 @@ def _stark_worker(rank, world, port, logn, lb, W, t, min_block, q):
         want, want_top = o.fri_prove(ocfg, cw.astype(np.uint64))
         got_roots = bytes(roots)
         ok = ok and [got_roots[32 * c:32 * c + 32] for c in range(W)] == [bytes(r) for r in want_roots]
+        from conftest import column_openings_bytes
+        want += column_openings_bytes(o, lde, want_top, N)
         ok = ok and bytes(proof[:plen.value]) == want and list(top)[:t] == want_top
     q.put((rank, bool(ok), rc, coll.errors))
     dist.destroy_process_group()
