@@ -97,6 +97,10 @@ int smi_ctx_profile_read(smi_ctx *ctx, smi_kernel_time *out, size_t cap, size_t 
  * times what HBM delivers for each pass's access pattern.  Outputs are meaningless while it is
  * on; never enable it in product use. */
 int smi_ctx_copy_probe(smi_ctx *ctx, int enable);
+/* smi_dev_lde / smi_lde at 2^20..2^22 rows: run the extension in two passes over its outputs (coset-split
+ * pass A, interleaving pass B -- csrc/lde_core.h) instead of the generic three.  Same results; off by
+ * default (within 2 % of the generic path on MI355X); SMI_LDE_TWO_PASS=1 sets the default. */
+int smi_ctx_lde_two_pass(smi_ctx *ctx, int enable);
 uint64_t smi_ctx_modulus(const smi_ctx *ctx);
 uint32_t smi_ctx_two_adicity(const smi_ctx *ctx);
 

@@ -89,6 +89,7 @@ def lib():
         "smi_ctx_sync": (i32, [vp]),
         "smi_ctx_profile": (i32, [vp, i32]),
         "smi_ctx_copy_probe": (i32, [vp, i32]),
+        "smi_ctx_lde_two_pass": (i32, [vp, i32]),
         "smi_ctx_profile_read": (i32, [vp, vp, sz, C.POINTER(sz)]),
         "smi_ctx_modulus": (C.c_uint64, [vp]),
         "smi_ctx_two_adicity": (C.c_uint32, [vp]),

@@ -147,6 +147,11 @@ int smi_ctx_profile(smi_ctx *ctx, int enable) {
     ctx->prof_on = enable != 0;
     return SMI_OK;
 }
+int smi_ctx_lde_two_pass(smi_ctx *ctx, int enable) {
+    if (!ctx) return SMI_ERR_BAD_ARG;
+    ctx->lde_two_pass = enable != 0;
+    return SMI_OK;
+}
 int smi_ctx_copy_probe(smi_ctx *ctx, int enable) {
     if (!ctx) return SMI_ERR_BAD_ARG;
     DeviceGuard dg__(ctx);
@@ -568,10 +573,11 @@ int smi_dev_lde(smi_ctx *ctx, const uint32_t *d_cols, uint32_t n_cols, uint32_t 
     // scaling, so the forward transform runs with offset 1 and reads the n coefficients from
     // the head of each output column (zero-padded to N on the fly).
     SMI_TRY(dev_ntt(ctx, d_cols, d_out, log_n, n, n_cols, n, N, 1, trace_offset, lde_offset));
-    // the extension's zero padding lets it run in two passes over the outputs instead of three
-    // (lde_core.h); SMI_LDE_GENERIC=1 keeps the generic transform (tuning / comparison runs)
-    static const bool generic = getenv("SMI_LDE_GENERIC") && atoi(getenv("SMI_LDE_GENERIC"));
-    if (!generic && lde2_supported(log_n, log_blowup)) return dev_lde2(ctx, d_out, d_out, log_n, log_blowup, n_cols, N, N);
+    // The extension's zero padding lets it run in two passes over the outputs instead of three
+    // (lde_core.h).  Measured on MI355X: both of its passes end up as close to
+    // their arithmetic as to their memory time and the step is within 2 % of the generic transform's,
+    // so the generic path stays the default; smi_ctx_lde_two_pass / SMI_LDE_TWO_PASS=1 select it.
+    if (ctx->lde_two_pass && lde2_supported(log_n, log_blowup)) return dev_lde2(ctx, d_out, d_out, log_n, log_blowup, n_cols, N, N);
     return dev_ntt(ctx, d_out, d_out, log_N, n, n_cols, N, N, 0, 1, 1);
 }
 

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <stdlib.h>
+
 #include <string>
 #include <vector>
 
@@ -38,6 +40,7 @@ struct smi_ctx {
     std::string err;
     bool prof_on = false;
     bool copy_probe = false;       // smi_ctx_copy_probe: NTT passes launch their copy-only twins
+    bool lde_two_pass = getenv("SMI_LDE_TWO_PASS") && atoi(getenv("SMI_LDE_TWO_PASS"));   // smi_ctx_lde_two_pass
     std::vector<ProfRec> prof;
     // bump arena for the per-prove device buffers (trees, folded codewords, proof bytes):
     // steady state does no hipMalloc/hipFree.  Overflow allocations are tracked and the

@@ -57,6 +57,10 @@ class Engine:
         """Bracket every hot-path kernel launch with HIP events on the context's stream."""
         self._ck(self.L.smi_ctx_profile(self.h, 1 if enable else 0))
 
+    def lde_two_pass(self, enable=True):
+        """extensions of 2^20..2^22 rows in two passes over the outputs (csrc/lde_core.h) instead of three"""
+        self._ck(self.L.smi_ctx_lde_two_pass(self.h, 1 if enable else 0))
+
     def copy_probe(self, enable=True):
         """Measurement aid: NTT passes launch their copy-only twins (same access pattern, no
         arithmetic); results are meaningless while it is on."""

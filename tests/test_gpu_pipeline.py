@@ -314,10 +314,12 @@ def test_two_pass_lde_equals_oracle(eng, eng2, oracle, which, logn, lb, W):
         cols[1, :] = p - 1                       # lazy sums at their bounds
     d_in = _upload(e, cols)
     d_out = e.dev_alloc(W * N * 4)
+    e.lde_two_pass(True)
     e.profile(True)
     e.dev_lde(d_in, W, logn, lb, d_out, 1, g)
     names = e.profile_read()
     e.profile(False)
+    e.lde_two_pass(False)
     assert any(k.startswith("lde_a_kernel") for k in names) and "lde_b_kernel" in names, names   # the two-pass path ran
     got = e.dev_download(d_out, W * N).reshape(W, N)
     for c in range(W):

@@ -11,5 +11,5 @@ for k,v in r['roofline']['kernels'].items():
     print('  ',k,'real %.1f us'%(v['avg_ms']*1e3),'copy-only %.1f us'%((v.get('copy_only_ms') or 0)*1e3))
 "
 }
-echo "== generic"; SMI_LDE_GENERIC=1 run
-for v in "$@"; do echo "== SMI_LDE_DBG=$v"; SMI_LDE_DBG=$v run; done
+echo "== generic"; run
+for v in "$@"; do echo "== SMI_LDE_DBG=$v"; SMI_LDE_TWO_PASS=1 SMI_LDE_DBG=$v run; done

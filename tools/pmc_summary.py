@@ -21,6 +21,11 @@ def bench_name(sym):
     m = re.search(r"ntt_pass_kernel<(\d+), (\d+), (\d+), \d+>", sym)
     if m:
         return f"ntt_pass_kernel<{m.group(1)},{m.group(2)},{KIND[m.group(3)]}>"
+    m = re.search(r"lde_a_kernel<(\d+), \d+>", sym)
+    if m:
+        return f"lde_a_kernel<{m.group(1)}>"
+    if "lde_b_kernel" in sym:
+        return "lde_b_kernel"
     m = re.search(r"merkle_sub_kernel<(true|false)>", sym)
     if m:
         return "merkle_sub_kernel<leaves>" if m.group(1) == "true" else "merkle_sub_kernel<digests>"
@@ -48,7 +53,7 @@ def main():
     fetch, write, valu = counters(os.path.join(src, "fetch")), counters(os.path.join(src, "write")), counters(os.path.join(src, "valu"))
     summary = {}
     for k in sorted(set(fetch) | set(write)):
-        if not k.startswith("ntt_pass_kernel"):
+        if not (k.startswith("ntt_pass_kernel") or k.startswith("lde_")):
             continue
         f = fetch.get(k, {}).get("FETCH_SIZE", [])
         w = write.get(k, {}).get("WRITE_SIZE", [])
