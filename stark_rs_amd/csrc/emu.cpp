@@ -91,6 +91,8 @@ struct EmuLauncher {
 
 }  // namespace
 
+static bool g_emu_defer_tw = false;
+extern "C" void emu_set_defer_tw(int on) { g_emu_defer_tw = on != 0; }
 extern "C" int emu_ntt(uint64_t p, uint64_t g, const uint32_t *in, uint32_t *out, uint32_t L, uint32_t n_in,
                        uint32_t batch, uint64_t in_stride, uint64_t out_stride, int inverse, uint64_t offset,
                        uint64_t post_scale) {
@@ -126,6 +128,7 @@ extern "C" int emu_ntt(uint64_t p, uint64_t g, const uint32_t *in, uint32_t *out
     std::vector<uint32_t> scratch((size_t)batch << L);
     rq.in = in; rq.out = out; rq.scratch = scratch.data();
     rq.L = L; rq.n_in = n_in; rq.batch = batch; rq.in_stride = in_stride; rq.out_stride = out_stride; rq.F = F;
+    rq.defer_tw = g_emu_defer_tw;
     EmuLauncher ln;
     return ntt_run(ln, rq) ? 0 : -1;
 }

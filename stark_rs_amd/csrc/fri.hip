@@ -426,10 +426,18 @@ int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, si
     uint32_t omega = (uint32_t)cfg->omega, offset = (uint32_t)cfg->offset;
     const uint32_t *cur = d_codeword;
     uint64_t cur_len = len;
-    // SMI_FRI_TAIL=0 keeps one set of launches per round to the end (comparison runs)
-    static const bool fused_tail = !(getenv("SMI_FRI_TAIL") && atoi(getenv("SMI_FRI_TAIL")) == 0);
+    // Codewords of at most this many elements finish in the fused tail launch (hash.hip, fri_tail_kernel).
+    // Measured on MI355X (2^25-point prove): from 2048 elements one workgroup is slower than the
+    // per-round launches, whose 64-leaf chunks spread a 2048-leaf tree over 32 CUs (FRI stage 4.55 vs 4.44 ms);
+    // from 512 -- the size the per-round path gives a single workgroup anyway -- the two are equal within noise.
+    // SMI_FRI_TAIL=<len> overrides (0: never).
+    static const uint64_t tail_len = [] {
+        const char *e = getenv("SMI_FRI_TAIL");
+        const uint64_t v = e ? (uint64_t)atoll(e) : 512;
+        return v > SMI_FRI_TAIL_MAX_LEN ? (uint64_t)SMI_FRI_TAIL_MAX_LEN : v;
+    }();
     for (uint64_t r = 0; r < R; r++) {
-        if (fused_tail && cur_len <= SMI_FRI_TAIL_MAX_LEN && R - r <= SMI_FRI_TAIL_MAX_ROUNDS) {
+        if (cur_len <= tail_len && R - r <= SMI_FRI_TAIL_MAX_ROUNDS) {
             // every remaining round in one workgroup launch (hash.hip, fri_tail_kernel)
             FriTailArgs ta;
             memset(&ta, 0, sizeof ta);

@@ -363,6 +363,7 @@ int dev_ntt(smi_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint32_t log_n,
         rq.q_plain = q;
         SMI_TRY(ctx_scale_tables(ctx, ninv, q, log_n, &rq.S));
     }
+    rq.defer_tw = ctx->ntt_defer_tw;
     if (ntt_make_plan(log_n, batch).np > 0) SMI_TRY(ctx_scratch(ctx, (size_t)batch << log_n, &rq.scratch));   // inter-pass buffer
     HipLauncher ln{ctx};
     if (!ntt_run(ln, rq)) return smi_fail(ctx, SMI_ERR_BAD_ARG, "ntt: multi-pass plan without its inter-pass buffer");

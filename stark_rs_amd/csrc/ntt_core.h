@@ -60,7 +60,7 @@ struct ScaleTables {      // c * q^i = lo[i & (2^h-1)] * hi[i >> h]   (Montgomer
     const uint32_t *lo, *hi;
     uint32_t h;
 };
-enum { NTT_FIRST = 1, NTT_PRE_SCALE = 2, NTT_POST_SCALE = 4 };
+enum { NTT_FIRST = 1, NTT_PRE_SCALE = 2, NTT_POST_SCALE = 4, NTT_TW_SKIP = 8, NTT_TW_IN = 16 };
 
 struct PassArgs {
     const uint32_t *in;
@@ -86,6 +86,11 @@ struct PassArgs {
     // columns b in [b_off, b_off + B >> shard_log) of the pass's [R][B] view as a strip [R][B >> shard_log];
     // addresses use the strip's row length, twiddles / scales / padding the global index.
     uint32_t shard_log, b_off;
+    // NTT_TW_SKIP: this (first) pass stores its outputs canonical and leaves its inter-pass twiddle
+    // w_m^(k b) to the next pass; NTT_TW_IN: this (middle) pass applies it to its loads -- the first pass
+    // of an extension is bound by arithmetic, the middle one by memory.  prev_logr = log2 of the
+    // previous pass's digit (k = sub-problem index mod 2^prev_logr).
+    uint32_t prev_logr;
 };
 
 // digit structure of the in-tile transform; s0 = 4 everywhere, so the 16 values a thread loads in
@@ -298,6 +303,21 @@ template <int LOGR, int LOGW, int KIND, int CAP> struct NttPass {
             const uint32_t *in = a.in + (uint64_t)batch * a.in_stride + t.in_base;
 #pragma unroll
             for (int i = 0; i < V; i++) v[i] = ld32(in, o0 + ((uint32_t)(i * (NT >> LOGW)) << ablog));
+            if (a.flags & NTT_TW_IN) {
+                // the previous pass's w_m'^(k b'), m' = 2^(L - Sp + prev_logr): k = its output digit = the low
+                // prev_logr bits of this tile's sub-problem index, b' = (row << blog) + column; along a
+                // thread's rows a geometric sequence whose ratio is the same for the whole tile
+                const uint32_t sub = (uint32_t)(t.in_base >> (a.L - a.Sp)), k = sub & ((1u << a.prev_logr) - 1u);
+                const uint32_t sh = a.T.K - (a.L - a.Sp + a.prev_logr);
+                uint32_t cur = two_level(a.T.lo, a.T.hi, a.T.h, (k * ((j0 << blog) + t.b0 + w)) << sh, a.F);
+                const uint32_t ratio = two_level(a.T.lo, a.T.hi, a.T.h, (k * ((uint32_t)(NT >> LOGW) << blog)) << sh, a.F);
+                const uint32_t rq = ratio * a.F.pinv;
+#pragma unroll
+                for (int i = 0; i < V; i++) {
+                    v[i] = mont_mul(v[i], cur, a.F);
+                    if (i + 1 < V) cur = mont_mul_c(cur, ratio, rq, a.F);
+                }
+            }
         }
     }
 
@@ -391,7 +411,7 @@ template <int LOGR, int LOGW, int KIND, int CAP> struct NttPass {
         // lookups per thread whatever NB is.
         uint32_t base_run = 0, gs = 0, gq = 0, gbi = 0, gbq = 0;   // first pass: g^kbase, g^(R/RL), g^RL
         uint32_t sc_run = 0, rq = 0, rbq = 0;                        // last pass: scale(kn_base) and ratios
-        if constexpr (!LAST) {
+        if (!LAST && !(a.flags & NTT_TW_SKIP)) {
             const uint32_t b = a.b_off + t.b0 + (tid & (W - 1)), sh = a.T.K - mlog;
             base_run = two_level(a.T.lo, a.T.hi, a.T.h, (b * blk_to_k(tid >> LOGW)) << sh, a.F);
             gs = two_level(a.T.lo, a.T.hi, a.T.h, (b << KSTEP_LOG) << sh, a.F);
@@ -426,6 +446,12 @@ template <int LOGR, int LOGW, int KIND, int CAP> struct NttPass {
                     // the thread's butterflies, see above).  A per-pass table of (w, Shoup quotient)
                     // pairs read with the data's coalescing saves 60 VALU ops per thread but triples
                     // the L2 -> L1 traffic of the pass; measured slower (2^25 x 4: 266 vs 247 us).
+                    if (a.flags & NTT_TW_SKIP) {   // the next pass multiplies as it loads
+#pragma unroll
+                        for (int kk = 0; kk < RL; kk++)
+                            st32(out, o0 + ((uint32_t)kk << (KSTEP_LOG + blog)), lz_canon_m(x[brev<SL>(kk)], m[brev<SL>(kk)], p));
+                        continue;
+                    }
                     uint32_t cur = base_run;
                     if (bi + 1 < NB) base_run = mont_mul_c(base_run, gbi, gbq, a.F);
 #pragma unroll

@@ -18,6 +18,7 @@ struct NttRequest {
     bool pre_scale;      // multiply input i by S(i)   (coset shift of a forward transform)
     bool post_scale;     // multiply output k by S(k)  (n^-1 * offset^-k of an inverse transform)
     uint32_t q_plain;    // ratio of the scale sequence S(i) = c * q^i (plain form)
+    bool defer_tw;       // three or more passes: the first pass's inter-pass twiddle is applied by the second as it loads
 };
 
 // Launcher concept:
@@ -49,6 +50,11 @@ template <class Launcher> inline bool ntt_run(Launcher &ln, const NttRequest &rq
         a.L = rq.L; a.Sp = consumed; a.n_in = rq.n_in;
         a.flags = (first ? NTT_FIRST : 0) | (first && rq.pre_scale ? NTT_PRE_SCALE : 0) |
                   (last && rq.post_scale ? NTT_POST_SCALE : 0);
+        if (rq.defer_tw && pl.np >= 3 && p == 0) a.flags |= NTT_TW_SKIP;
+        if (rq.defer_tw && pl.np >= 3 && p == 1) {
+            a.flags |= NTT_TW_IN;
+            a.prev_logr = (uint32_t)pl.logr[0];
+        }
         a.d0_log = (uint32_t)pl.logr[0];
         a.n_mid = (uint32_t)(pl.np - 2);
         for (int d = 0; d < pl.np - 2; d++) a.mid_log[d] = (uint32_t)pl.logr[1 + d];

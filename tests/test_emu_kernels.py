@@ -221,3 +221,27 @@ def test_field_setup_rejects_composite_moduli(emu):
     args = (x.ctypes.data_as(u32p), out.ctypes.data_as(u32p), 4, 16, 1, 16, 16, 0, 1, 1)
     assert emu.emu_ntt(20481, 3, *args) == -1
     assert emu.emu_ntt(P, G, *args) == 0 and emu.emu_ntt(P2, G2, *args) == 0
+
+
+def test_emulated_ntt_deferred_first_twiddle(emu, oracle):
+    """three-pass plans (2^21 x 2 columns) with the first pass's inter-pass twiddle applied by the second
+    pass as it loads (NTT_TW_SKIP / NTT_TW_IN of csrc/ntt_core.h): same results, zero-padded (an
+    extension) and full, forward and inverse."""
+    o = oracle
+    L = 21
+    n = 1 << L
+    emu.emu_set_defer_tw(1)
+    try:
+        for p, g in ((P, G), (P2, G2)):
+            w = o.ff_prim_nth_root_g(n, p, g)
+            a, b = o.splitmix64(7, n) % np.uint64(p), np.full(n, p - 1, dtype=np.uint64)
+            both = np.concatenate([a, b])
+            got = _ntt(emu, p, g, both, L, n, 0, 3, batch=2).reshape(2, n)
+            assert np.array_equal(got[0], o.fast_coset_ntt(a, n, w, 3, p)) and np.array_equal(got[1], o.fast_coset_ntt(b, n, w, 3, p))
+            got = _ntt(emu, p, g, both, L, n // 8, 0, 1, batch=2, in_stride=n).reshape(2, n)       # zero-padded: an extension
+            assert np.array_equal(got[0], o.fast_coset_ntt(a[:n // 8], n, w, 1, p))
+            assert np.array_equal(got[1], o.fast_coset_ntt(b[:n // 8], n, w, 1, p))
+            got = _ntt(emu, p, g, both, L, n, 1, 1, batch=2).reshape(2, n)
+            assert np.array_equal(got[0], o.fast_intt(a, w, 1, p)) and np.array_equal(got[1], o.fast_intt(b, w, 1, p))
+    finally:
+        emu.emu_set_defer_tw(0)
