@@ -427,10 +427,12 @@ int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, si
     const uint32_t *cur = d_codeword;
     uint64_t cur_len = len;
     // Codewords of at most this many elements finish in the fused tail launch (hash.hip, fri_tail_kernel).
-    // Measured on MI355X (2^25-point prove): from 2048 elements one workgroup is slower than the
-    // per-round launches, whose 64-leaf chunks spread a 2048-leaf tree over 32 CUs (FRI stage 4.55 vs 4.44 ms);
-    // from 512 -- the size the per-round path gives a single workgroup anyway -- the two are equal within noise.
-    // SMI_FRI_TAIL=<len> overrides (0: never).
+    // Measured on MI355X (2^25-point prove): the FRI stage is 4.44..4.69 ms with the tail
+    // off, from 512, from 1024 or from 2048 elements alike -- the differences are inside the run-to-run
+    // spread of +-0.1 ms, because the tail's cost is the serial chain tree -> alpha -> fold, not launch
+    // overhead.  Default: 512, the size the per-round path hands to a single workgroup anyway (above it
+    // the per-round path spreads a tree's 64-leaf chunks over several CUs).  SMI_FRI_TAIL=<len> overrides
+    // (0: never).
     static const uint64_t tail_len = [] {
         const char *e = getenv("SMI_FRI_TAIL");
         const uint64_t v = e ? (uint64_t)atoll(e) : 512;

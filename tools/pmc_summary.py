@@ -43,14 +43,8 @@ def counters(run_dir):
     return out
 
 
-def main():
-    src, tag = sys.argv[1], sys.argv[2]
-    dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
-    os.makedirs(dst, exist_ok=True)
-    for sub, name in (("stats", "lde"), ("prove", "prove")):
-        for path in glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True):
-            shutil.copy(path, os.path.join(dst, f"{tag}_{name}_kernel_stats.csv"))
-    fetch, write, valu = counters(os.path.join(src, "fetch")), counters(os.path.join(src, "write")), counters(os.path.join(src, "valu"))
+def summarise(src, suffix=""):
+    fetch, write, valu = (counters(os.path.join(src, d + suffix)) for d in ("fetch", "write", "valu"))
     summary = {}
     for k in sorted(set(fetch) | set(write)):
         if not (k.startswith("ntt_pass_kernel") or k.startswith("lde_")):
@@ -66,10 +60,39 @@ def main():
         if v.get("SQ_INSTS_VALU") and v.get("SQ_WAVES"):
             e["valu_insts_per_wave"] = sum(v["SQ_INSTS_VALU"]) / sum(v["SQ_WAVES"])
         summary[k] = e
-    note = ("rocprofv3 --pmc in separate passes (FETCH_SIZE | WRITE_SIZE | SQ_INSTS_VALU SQ_WAVES) over "
-            "`bench.py --no-extras --steps 20`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B "
-            "requests at 64 B); KB units; averages over all launches of the kernel in the run")
-    json.dump({"note": note, **summary}, open(os.path.join(dst, f"{tag}_lde_pmc.json"), "w"), indent=1)
+    return summary
+
+
+NOTE = ("rocprofv3 --pmc in separate passes (FETCH_SIZE | WRITE_SIZE | SQ_INSTS_VALU SQ_WAVES) over "
+        "`bench.py --no-extras`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B "
+        "requests at 64 B); KB units; averages over all launches of the kernel in the run")
+
+
+def main():
+    src, tag = sys.argv[1], sys.argv[2]
+    dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    os.makedirs(dst, exist_ok=True)
+    if len(sys.argv) > 3 and sys.argv[3] == "two_pass":       # the opt-in two-pass extension, SMI_LDE_TWO_PASS=1
+        for path in glob.glob(os.path.join(src, "stats2", "**", "*kernel_stats.csv"), recursive=True):
+            shutil.copy(path, os.path.join(dst, f"{tag}_lde_two_pass_kernel_stats.csv"))
+        summary = summarise(src, "2")
+        json.dump({"note": NOTE + "; SMI_LDE_TWO_PASS=1", **summary}, open(os.path.join(dst, f"{tag}_lde_two_pass_pmc.json"), "w"), indent=1)
+        traffic_path = os.path.join(dst, "pmc_traffic.json")
+        traffic = json.load(open(traffic_path)) if os.path.exists(traffic_path) else {}
+        traffic.update({k: v for k, v in summary.items() if k.startswith("lde_")})
+        json.dump(traffic, open(traffic_path, "w"), indent=1)
+        bj = os.path.join(src, "bench_stats2.json")
+        if os.path.exists(bj):
+            lines = [l for l in open(bj) if l.startswith("{")]
+            if lines:
+                open(os.path.join(dst, f"{tag}_two_pass_bench_under_rocprof.json"), "w").write(lines[-1])
+        print(json.dumps(summary, indent=1))
+        return
+    for sub, name in (("stats", "lde"), ("prove", "prove")):
+        for path in glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True):
+            shutil.copy(path, os.path.join(dst, f"{tag}_{name}_kernel_stats.csv"))
+    summary = summarise(src)
+    json.dump({"note": NOTE, **summary}, open(os.path.join(dst, f"{tag}_lde_pmc.json"), "w"), indent=1)
     json.dump(summary, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
     bj = os.path.join(src, "bench_stats.json")
     if os.path.exists(bj):

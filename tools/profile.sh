@@ -10,6 +10,7 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 BENCH="python3 bench.py --no-extras --steps 20 --warmup 3"
+BENCH2="python3 bench.py --no-extras --steps 10 --warmup 3"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o lde -- $BENCH > $OUT/bench_stats.json 2> $OUT/stats.err
 echo "stats done"
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/fetch -o lde -- $BENCH > /dev/null 2> $OUT/fetch.err
@@ -21,3 +22,12 @@ echo "valu done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prove -o prove -- python3 tools/kbench.py prove:22:3:4 > $OUT/prove.log 2> $OUT/prove.err
 echo "prove done"
 python3 tools/pmc_summary.py $OUT $TAG
+# the opt-in two-pass extension (csrc/lde_core.h): kernel stats + traffic, under its own tag
+export SMI_LDE_TWO_PASS=1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats2 -o lde2 -- $BENCH2 > $OUT/bench_stats2.json 2> $OUT/stats2.err
+rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/fetch2 -o lde2 -- $BENCH2 > /dev/null 2> $OUT/fetch2.err
+rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/write2 -o lde2 -- $BENCH2 > /dev/null 2> $OUT/write2.err
+rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES -d $OUT/valu2 -o lde2 -- $BENCH2 > /dev/null 2> $OUT/valu2.err
+unset SMI_LDE_TWO_PASS
+echo "two-pass done"
+python3 tools/pmc_summary.py $OUT $TAG two_pass
