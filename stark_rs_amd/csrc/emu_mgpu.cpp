@@ -274,9 +274,11 @@ extern "C" int emu_mgpu_lde(uint64_t p, uint64_t g, const smi_mgpu_coll *ops, in
     EmuDev d(p, g);
     EmuColl c(*ops);
     uint32_t *blocks = nullptr;
-    const int rc = mg_lde_blocks(d, c, rank, world, trace, n_cols, log_n, log_b, trace_offset, lde_offset, &blocks);
+    size_t stride = 0;
+    const int rc = mg_lde_blocks(d, c, rank, world, trace, n_cols, log_n, log_b, trace_offset, lde_offset, &blocks, &stride, 2);
     if (rc != SMI_OK) return rc;
-    memcpy(out_blocks, blocks, (((size_t)n_cols << (log_n + log_b)) / (size_t)world) * 4);
+    const size_t blk = ((size_t)1 << (log_n + log_b)) / (size_t)world;
+    for (uint32_t col = 0; col < n_cols; col++) memcpy(out_blocks + col * blk, blocks + col * stride, blk * 4);
     return SMI_OK;
 }
 

@@ -375,9 +375,12 @@ int smi_mgpu_lde(smi_mgpu *m, const uint32_t *d_trace_cols, uint32_t n_cols, uin
     DeviceGuard dg__(m->ctx);
     SMI_TRY(m->dev.reset());
     uint32_t *blocks = nullptr;
-    SMI_TRY(mg_lde_blocks(m->dev, *m->coll, m->rank, m->world, d_trace_cols, n_cols, log_n, log_blowup, trace_offset, lde_offset, &blocks));
+    size_t stride = 0;
+    // the entry point of its own always shards (shard_from = 2): its caller asked for the sharded extension
+    SMI_TRY(mg_lde_blocks(m->dev, *m->coll, m->rank, m->world, d_trace_cols, n_cols, log_n, log_blowup, trace_offset, lde_offset, &blocks,
+                          &stride, 2));
     const size_t blk = ((size_t)1 << (log_n + log_blowup)) / (size_t)m->world;
-    return m->dev.copy(d_out_blocks, blocks, (size_t)n_cols * blk * 4);
+    return m->dev.copy_rows(d_out_blocks, blk * 4, blocks, stride * 4, blk * 4, n_cols);
 }
 
 int smi_mgpu_ntt(smi_mgpu *m, uint32_t *d_strip, uint32_t *d_out, uint32_t log_n, int inverse, uint64_t offset) {

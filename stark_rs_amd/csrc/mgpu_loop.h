@@ -276,20 +276,27 @@ inline int mg_fri_run(MgDev &d, MgColl &coll, int rank, int G, const smi_fri_cfg
     return SMI_OK;
 }
 
-// This rank's natural-order block [rank N/G, (rank+1) N/G) of the extension of every column
-// (W x N/G elements, column stride N/G).  trace: all W columns of n residues, on every rank.
+// This rank's natural-order block [rank N/G, (rank+1) N/G) of the extension of every column: column c
+// starts at *blocks_out + c * *stride_out.  trace: all W columns of n residues, on every rank.
+// Sharding by (column, coset) units moves (G-1)/G of the extended trace once over the links: per rank
+// (G-1)/G^2 of W*N*4 bytes spread over G-1 links.  At G = 8 that is 8 MB per link (0.1 ms) for an
+// eighth of the transform work; at G = 2 it would be 128 MB over ONE link (about 1.8 ms at 70 GB/s per
+// direction) to save 0.4 ms of a 0.8 ms extension -- so up to 2 ranks every rank extends all columns
+// itself (no exchange) and only the hashing is sharded; from 4 ranks on the extension is sharded too.
 inline int mg_lde_blocks(MgDev &d, MgColl &coll, int rank, int G, const uint32_t *trace, uint32_t W, uint32_t log_n, uint32_t log_b,
-                         uint64_t trace_offset, uint64_t lde_offset, uint32_t **blocks_out) {
+                         uint64_t trace_offset, uint64_t lde_offset, uint32_t **blocks_out, size_t *stride_out, int shard_from = 4) {
     using namespace mg;
     const uint64_t n = 1ull << log_n, B = 1ull << log_b, U = (uint64_t)W * B;
     const uint32_t p = d.prime();
-    if (G == 1) {   // nothing to share: the ordinary batched extension
+    if (G < shard_from || G == 1) {   // the ordinary batched extension; this rank's blocks are views into it
         uint32_t *ext = (uint32_t *)d.alloc((size_t)W * n * B * 4);
         if (!ext) return d.fail(SMI_ERR_OOM, "mgpu: extension");
         MG_TRY(d.lde(trace, W, log_n, log_b, trace_offset, lde_offset, ext));
-        *blocks_out = ext;
+        *blocks_out = ext + (size_t)rank * ((n * B) / (uint64_t)G);
+        *stride_out = (size_t)(n * B);
         return SMI_OK;
     }
+    *stride_out = (size_t)((n * B) / (uint64_t)G);
     if (U % (uint64_t)G || n % (uint64_t)G) return d.fail(SMI_ERR_BAD_ARG, "mgpu: columns x blowup and the trace length must be multiples of the world size");
     const uint64_t upg = U / G, u0 = (uint64_t)rank * upg, nq = n / G;
     const uint64_t c_lo = u0 / B, c_hi = (u0 + upg - 1) / B, nc = c_hi - c_lo + 1;
@@ -378,8 +385,8 @@ inline int mg_stark_prove(MgDev &d, MgColl &coll, int rank, int G, const smi_sta
     if (!blk) return d.fail(SMI_ERR_BAD_ARG, "mgpu: more ranks than leaves");
     MG_TRY(d.reset());
     uint32_t *ext = nullptr;
-    MG_TRY(mg_lde_blocks(d, coll, rank, G, trace, W, cfg.log_n, cfg.log_blowup, cfg.trace_offset, cfg.lde_offset, &ext));
-    const size_t col_stride = G == 1 ? N : blk;
+    size_t col_stride = 0;
+    MG_TRY(mg_lde_blocks(d, coll, rank, G, trace, W, cfg.log_n, cfg.log_blowup, cfg.trace_offset, cfg.lde_offset, &ext, &col_stride));
     // one tree per column over this rank's leaves (one element per leaf, src/fri.rs:118-121), one set of launches
     const size_t tree_stride = 2 * blk * 32;
     uint8_t *trees = (uint8_t *)d.alloc(tree_stride * W);
