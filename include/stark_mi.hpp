@@ -9,6 +9,7 @@
 #pragma once
 #include <cstring>
 #include <memory>
+#include <array>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -529,6 +530,63 @@ struct Trace {
         for (size_t c = 0; c < num_columns; c++) res[c].assign(out.begin() + c * (n << log_blowup), out.begin() + (c + 1) * (n << log_blowup));
         return res;
     }
+};
+
+// Multi-GPU prover (one process per GPU; csrc/mgpu.hip): the communicator over the ranks of a node and
+// Fri::prove / the build-defined prove / one transform sharded across them.  Device pointers in,
+// the reference's serialized ProofStream out -- on every rank.  `id` = smi_mgpu_unique_id's 128 bytes
+// from rank 0, carried to the other ranks by the launcher.
+class MultiGpu {
+  public:
+    static std::array<uint8_t, SMI_MGPU_ID_BYTES> unique_id() {
+        std::array<uint8_t, SMI_MGPU_ID_BYTES> id{};
+        check(smi_mgpu_unique_id(id.data()));
+        return id;
+    }
+    MultiGpu(const FiniteField &f, const std::array<uint8_t, SMI_MGPU_ID_BYTES> &id, int rank, int world) : ctx_(f.ctx()) {
+        check(smi_mgpu_create(ctx_, id.data(), rank, world, &m_), ctx_);
+    }
+    MultiGpu(const MultiGpu &) = delete;
+    MultiGpu &operator=(const MultiGpu &) = delete;
+    ~MultiGpu() { smi_mgpu_destroy(m_); }
+    // Fri::prove (src/fri.rs:250-311) of the codeword this rank holds block `rank` of
+    std::vector<size_t> fri_prove(const smi_fri_cfg &cfg, const uint32_t *d_block, size_t block_len, ProofStream &proof_stream) {
+        uint8_t *bytes = nullptr;
+        size_t len = 0;
+        std::vector<uint64_t> top(cfg.num_colinearity_tests ? cfg.num_colinearity_tests : 1);
+        check(smi_mgpu_fri_prove(m_, &cfg, d_block, block_len, &bytes, &len, top.data()), ctx_);
+        ProofStream got = ProofStream::deserialize(std::vector<uint8_t>(bytes, bytes + len));
+        smi_free(bytes);
+        for (auto &o : got.objects) proof_stream.push(o);
+        return std::vector<size_t>(top.begin(), top.begin() + cfg.num_colinearity_tests);
+    }
+    // trace -> (column roots, proof bytes): smi_dev_stark_prove over the ranks
+    std::vector<uint8_t> stark_prove(const smi_stark_cfg &cfg, const uint32_t *d_trace_cols, std::vector<Hash> &column_roots,
+                                     std::vector<size_t> &top_indices) {
+        std::vector<uint8_t> roots(32 * (size_t)cfg.n_cols);
+        std::vector<uint64_t> top(cfg.num_colinearity_tests ? cfg.num_colinearity_tests : 1);
+        uint8_t *bytes = nullptr;
+        size_t len = 0;
+        check(smi_mgpu_stark_prove(m_, &cfg, d_trace_cols, roots.data(), &bytes, &len, top.data()), ctx_);
+        std::vector<uint8_t> proof(bytes, bytes + len);
+        smi_free(bytes);
+        column_roots.clear();
+        for (uint32_t c = 0; c < cfg.n_cols; c++) {
+            Hash h;
+            std::memcpy(h.b, roots.data() + 32 * c, 32);
+            column_roots.push_back(h);
+        }
+        top_indices.assign(top.begin(), top.begin() + cfg.num_colinearity_tests);
+        return proof;
+    }
+    // one 2^log_n-point transform over the ranks (layouts: include/stark_mi.h, smi_mgpu_ntt)
+    void ntt(uint32_t *d_strip, uint32_t *d_out, uint32_t log_n, bool inverse = false, uint64_t offset = 1) {
+        check(smi_mgpu_ntt(m_, d_strip, d_out, log_n, inverse ? 1 : 0, offset), ctx_);
+    }
+
+  private:
+    smi_ctx *ctx_;
+    smi_mgpu *m_ = nullptr;
 };
 
 }  // namespace starkmi

@@ -146,6 +146,28 @@ int main() {
         }
         EXPECT(same);
     }
+    // multi-GPU wrapper over a one-rank RCCL communicator: the sharded Fri::prove must give the same
+    // ProofStream objects as Fri::prove on the host-buffer path (src/fri.rs:250-311)
+    {
+        const size_t n = 256;
+        FieldElement omega = field.prim_nth_root(n), offset = field.new_element(3);
+        Fri fri(omega, offset, n, 8, 5);
+        std::vector<uint64_t> cw(n);
+        for (size_t i = 0; i < n; i++) cw[i] = (i * i + 7) % P;
+        ProofStream ps_host;
+        FiatShamir fs;
+        std::vector<size_t> top_host = fri.prove(elements_of(cw, field), fs, ps_host);
+        uint32_t *d_cw = nullptr;
+        check(smi_dev_alloc(field.ctx(), n * 4, (void **)&d_cw), field.ctx());
+        check(smi_dev_upload_u64(field.ctx(), cw.data(), n, d_cw, 0), field.ctx());
+        MultiGpu mg(field, MultiGpu::unique_id(), 0, 1);
+        ProofStream ps_dev;
+        smi_fri_cfg cfg{omega.value, offset.value, n, 8, 5};
+        std::vector<size_t> top_dev = mg.fri_prove(cfg, d_cw, n, ps_dev);
+        EXPECT(top_dev == top_host);
+        EXPECT(ps_dev.serialize() == ps_host.serialize());
+        check(smi_dev_free(field.ctx(), d_cw), field.ctx());
+    }
     std::printf(failures ? "FAILED (%d)\n" : "ALL PASSED\n", failures);
     return failures ? 1 : 0;
 }
