@@ -22,11 +22,15 @@
 
 __device__ __forceinline__ size_t level_offset(size_t n, uint32_t lvl) { return 2 * n - ((2 * n) >> lvl); }
 
-template <bool FROM_ELEMS>
+// KT > 0: the number of levels per lane is a compile-time constant (the loops below unroll, the stash
+// slots become constants); KT = 0: taken from the argument.  ROWS: the row-leaf path (runtime width) is
+// compiled in -- the element-leaf instantiation the prover lives in carries neither.
+template <bool FROM_ELEMS, int KT, bool ROWS>
 __global__ __launch_bounds__(SMI_HASH_THREADS) void merkle_sub_kernel(const uint32_t *__restrict__ elems, uint4 *nodes,
                                                                         size_t n, uint32_t lvl_in, size_t count_in,
-                                                                        uint32_t K, size_t elem_stride, size_t node_stride,
+                                                                        uint32_t K_arg, size_t elem_stride, size_t node_stride,
                                                                         uint32_t row_cols, size_t row_stride) {
+    const uint32_t K = KT ? (uint32_t)KT : K_arg;
     extern __shared__ __attribute__((aligned(16))) uint32_t stash[];  // [1<<K][8][SMI_HASH_THREADS]
     // blockIdx.y = tree of a batch of equally sized trees (e.g. the columns of a trace)
     elems += (size_t)blockIdx.y * elem_stride;
@@ -48,7 +52,7 @@ __global__ __launch_bounds__(SMI_HASH_THREADS) void merkle_sub_kernel(const uint
 #pragma unroll
         for (int w = 0; w < 8; w++) d[w] = stash[(slot * 8 + w) * SMI_HASH_THREADS + tid];
     };
-    if (FROM_ELEMS && row_cols) {
+    if (FROM_ELEMS && ROWS && row_cols) {
         // row leaves: leaf i = Hash::from_field_elements(row i) over row_cols <= 4 columns row_stride
         // apart (wider rows are hashed by row_hash_kernel and enter as digests)
         for (uint32_t i = 0; i < per; i += 2) {
@@ -70,6 +74,7 @@ __global__ __launch_bounds__(SMI_HASH_THREADS) void merkle_sub_kernel(const uint
             }
         }
     } else if (FROM_ELEMS) {
+#pragma unroll
         for (uint32_t i = 0; i < per; i += 2) {
             uint32_t d0[8], d1[8];
             if (i + 1 < per) {
@@ -82,6 +87,7 @@ __global__ __launch_bounds__(SMI_HASH_THREADS) void merkle_sub_kernel(const uint
             }
         }
     } else {
+#pragma unroll
         for (uint32_t i = 0; i < per; i++) {
             const uint4 *src = nodes + 2 * (level_offset(n, lvl_in) + first + i);
             const uint4 a = src[0], b = src[1];
@@ -89,9 +95,11 @@ __global__ __launch_bounds__(SMI_HASH_THREADS) void merkle_sub_kernel(const uint
             for (int w = 0; w < 8; w++) stash[(i * 8 + w) * SMI_HASH_THREADS + tid] = w < 4 ? (&a.x)[w] : (&b.x)[w - 4];
         }
     }
+#pragma unroll
     for (uint32_t j = 1; j <= K; j++) {
         const uint32_t cnt = per >> j;
         uint4 *dst = nodes + 2 * (level_offset(n, lvl_in + j) + (t << (K - j)));
+#pragma unroll
         for (uint32_t q = 0; q < cnt; q += 2) {
             uint32_t l0[8], r0[8], d0[8];
             get(2 * q, l0);
@@ -481,10 +489,18 @@ static int launch_merkle_impl(smi_ctx *ctx, const uint32_t *d_elems, size_t n, u
         ProfScope ps(ctx, from_elems ? "merkle_sub_kernel<leaves>" : "merkle_sub_kernel<digests>",
                      ((from_elems ? 4.0 * (row_cols ? row_cols : 1) : 32.0) * (double)count + 32.0 * produced) * n_trees);
         const dim3 grid(blocks_for(threads), n_trees);
-        if (from_elems)
-            merkle_sub_kernel<true><<<grid, SMI_HASH_THREADS, lds, ctx->stream>>>(d_elems, nodes, n, 0, count, K, elem_stride, node_stride, row_cols, row_stride);
+        // the hot shapes (element leaves or digests, two levels per lane) have instantiations of their own
+        static const bool generic_only = getenv("SMI_MERKLE_GENERIC") && atoi(getenv("SMI_MERKLE_GENERIC"));
+        if (from_elems && row_cols)
+            merkle_sub_kernel<true, 0, true><<<grid, SMI_HASH_THREADS, lds, ctx->stream>>>(d_elems, nodes, n, 0, count, K, elem_stride, node_stride, row_cols, row_stride);
+        else if (from_elems && K == 2 && !generic_only)
+            merkle_sub_kernel<true, 2, false><<<grid, SMI_HASH_THREADS, lds, ctx->stream>>>(d_elems, nodes, n, 0, count, K, elem_stride, node_stride, 0, 0);
+        else if (from_elems)
+            merkle_sub_kernel<true, 0, false><<<grid, SMI_HASH_THREADS, lds, ctx->stream>>>(d_elems, nodes, n, 0, count, K, elem_stride, node_stride, 0, 0);
+        else if (K == 2 && !generic_only)
+            merkle_sub_kernel<false, 2, false><<<grid, SMI_HASH_THREADS, lds, ctx->stream>>>(nullptr, nodes, n, lvl, count, K, 0, node_stride, 0, 0);
         else
-            merkle_sub_kernel<false><<<grid, SMI_HASH_THREADS, lds, ctx->stream>>>(nullptr, nodes, n, lvl, count, K, 0, node_stride, 0, 0);
+            merkle_sub_kernel<false, 0, false><<<grid, SMI_HASH_THREADS, lds, ctx->stream>>>(nullptr, nodes, n, lvl, count, K, 0, node_stride, 0, 0);
         HIP_TRY(ctx, hipGetLastError());
         from_elems = false;
         lvl += K;
