@@ -572,13 +572,16 @@ int smi_dev_lde(smi_ctx *ctx, const uint32_t *d_cols, uint32_t n_cols, uint32_t 
     // lde_offset, src/univariate/mod.rs:99-113) is fused into the inverse transform's output
     // scaling, so the forward transform runs with offset 1 and reads the n coefficients from
     // the head of each output column (zero-padded to N on the fly).
-    SMI_TRY(dev_ntt(ctx, d_cols, d_out, log_n, n, n_cols, n, N, 1, trace_offset, lde_offset));
-    // The extension's zero padding lets it run in two passes over the outputs instead of three
-    // (lde_core.h).  Measured on MI355X: both of its passes end up as close to
-    // their arithmetic as to their memory time and the step is within 2 % of the generic transform's,
-    // so the generic path stays the default; smi_ctx_lde_two_pass / SMI_LDE_TWO_PASS=1 select it.
-    if (ctx->lde_two_pass && lde2_supported(log_n, log_blowup)) return dev_lde2(ctx, d_out, d_out, log_n, log_blowup, n_cols, N, N);
-    return dev_ntt(ctx, d_out, d_out, log_N, n, n_cols, N, N, 0, 1, 1);
+    auto extend = [&](const uint32_t *cols, uint32_t w, uint32_t *out) -> int {
+        SMI_TRY(dev_ntt(ctx, cols, out, log_n, n, w, n, N, 1, trace_offset, lde_offset));
+        // The extension's zero padding lets it run in two passes over the outputs instead of three
+        // (lde_core.h).  Measured on MI355X: both of its passes end up as close to
+        // their arithmetic as to their memory time and the step is within 2 % of the generic transform's,
+        // so the generic path stays the default; smi_ctx_lde_two_pass / SMI_LDE_TWO_PASS=1 select it.
+        if (ctx->lde_two_pass && lde2_supported(log_n, log_blowup)) return dev_lde2(ctx, out, out, log_n, log_blowup, w, N, N);
+        return dev_ntt(ctx, out, out, log_N, n, w, N, N, 0, 1, 1);
+    };
+    return extend(d_cols, n_cols, d_out);
 }
 
 static int host_ntt(smi_ctx *ctx, const uint64_t *in, size_t n_in, uint64_t *out, uint32_t log_n, int inverse, uint64_t offset) {
