@@ -206,6 +206,14 @@ int smi_fri_prove(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint64_t *codeword
                   size_t *proof_len, uint64_t *top_indices);
 /* The `codewords` Fri::commit returns (src/fri.rs:153-155): their count, one of them (out may be
  * NULL to query *len), and MerkleTree::open on a round's retained tree. */
+/* Fri::verify (src/fri.rs:313-504) of a serialized ProofStream against a fresh FiatShamir: *accept = 1 where the
+ * reference returns true, 0 where it prints a reason and returns false (smi_last_error has the reason); a
+ * reference panic (e.g. a last codeword whose length is not a power of two, src/merkle.rs:13-16) is that panic's
+ * status.  pv_indices / pv_values (optional, 2*t entries each) receive the (index, value) pairs the reference
+ * pushes to polynomial_values.  Leaf hashes and authentication paths are checked in device batches, the last
+ * layer's degree by an inverse + forward NTT; SMI_ERR_NOT_GEOMETRIC if cfg's omega does not generate the domain. */
+int smi_fri_verify(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint8_t *proof, size_t proof_len, int *accept, uint64_t *pv_indices,
+                   uint64_t *pv_values, size_t *n_pv);
 int smi_fri_run_num_codewords(const smi_fri_run *run, size_t *n);
 int smi_fri_run_codeword(smi_fri_run *run, size_t round, uint64_t *out, size_t *len);
 int smi_fri_run_open(smi_fri_run *run, size_t round, size_t index, uint8_t *path, size_t *depth);
@@ -286,6 +294,13 @@ typedef struct {
 } smi_stark_cfg;
 int smi_dev_stark_prove(smi_ctx *ctx, const smi_stark_cfg *cfg, const uint32_t *d_trace_cols, uint8_t *column_roots,
                         uint8_t **proof, size_t *proof_len, uint64_t *top_indices, double *stage_ms);
+
+/* Verifier of smi_dev_stark_prove / smi_mgpu_stark_prove (column trees): Fri::verify of the leading objects on the
+ * domain lde_offset * <w_N> and, with cfg->open_columns, the column openings -- every authentication path against
+ * its column root (column_roots: n_cols x 32) and sum_c weight_c * col_c[a] against the layer-0 triple -- with
+ * the weights re-derived from the column roots.  *accept as in smi_fri_verify. */
+int smi_stark_verify(smi_ctx *ctx, const smi_stark_cfg *cfg, const uint8_t *column_roots, const uint8_t *proof, size_t proof_len,
+                     int *accept);
 
 /* Four-step NTT building blocks for one transform sharded over G GPUs: one
  * process per GPU; the all-to-all between the two local steps belongs to the caller

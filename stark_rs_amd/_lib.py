@@ -124,6 +124,8 @@ def lib():
         "smi_fri_fold": (i32, [vp, vp, sz, C.c_uint64, C.c_uint64, C.c_uint64, vp]),
         "smi_fri_commit": (i32, [vp, C.POINTER(FriCfg), vp, sz, vp, vp, vp, C.POINTER(sz), C.POINTER(vp)]),
         "smi_fri_prove": (i32, [vp, C.POINTER(FriCfg), vp, sz, C.POINTER(vp), C.POINTER(sz), vp]),
+        "smi_fri_verify": (i32, [vp, C.POINTER(FriCfg), C.c_char_p, sz, C.POINTER(i32), vp, vp, C.POINTER(sz)]),
+        "smi_stark_verify": (i32, [vp, C.POINTER(StarkCfg), vp, C.c_char_p, sz, C.POINTER(i32)]),
         "smi_fri_run_num_codewords": (i32, [vp, C.POINTER(sz)]),
         "smi_fri_run_codeword": (i32, [vp, sz, vp, C.POINTER(sz)]),
         "smi_fri_run_open": (i32, [vp, sz, sz, vp, C.POINTER(sz)]),

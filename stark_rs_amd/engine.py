@@ -273,6 +273,25 @@ class Engine:
         return b, [int(v) for v in top[:cfg.num_colinearity_tests]]
 
     # ---- device-resident calls (pointers are ints)
+    def fri_verify(self, cfg, proof: bytes):
+        """Fri::verify (src/fri.rs:313-504) -> (accept, [(index, value)], reason); a reference panic raises."""
+        t = int(cfg.num_colinearity_tests)
+        pi, pv = np.zeros(2 * t + 2, dtype=np.uint64), np.zeros(2 * t + 2, dtype=np.uint64)
+        acc, n = C.c_int(), C.c_size_t()
+        self._ck(self.L.smi_fri_verify(self.h, C.byref(cfg), proof, len(proof), C.byref(acc), pi.ctypes.data, pv.ctypes.data, C.byref(n)))
+        why = "" if acc.value else self.L.smi_last_error(self.h).decode()
+        return bool(acc.value), [(int(pi[i]), int(pv[i])) for i in range(n.value)], why
+
+    def stark_verify(self, proof: bytes, column_roots, n_cols, log_n, log_blowup, num_colinearity_tests, trace_offset=1,
+                     lde_offset=None, open_columns=False):
+        """verifier of dev_stark_prove / MultiGpu.stark_prove -> (accept, reason)"""
+        cfg = _lib.StarkCfg(log_n, log_blowup, n_cols, 0, trace_offset, self.g if lde_offset is None else lde_offset,
+                            num_colinearity_tests, 1 if open_columns else 0)
+        roots = np.ascontiguousarray(np.frombuffer(b"".join(bytes(r) for r in column_roots), dtype=np.uint8))
+        acc = C.c_int()
+        self._ck(self.L.smi_stark_verify(self.h, C.byref(cfg), roots.ctypes.data, proof, len(proof), C.byref(acc)))
+        return bool(acc.value), ("" if acc.value else self.L.smi_last_error(self.h).decode())
+
     def dev_alloc(self, nbytes):
         d = vp()
         self._ck(self.L.smi_dev_alloc(self.h, nbytes, C.byref(d)))

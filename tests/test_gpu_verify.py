@@ -1,0 +1,122 @@
+"""GPU: Fri::verify behind the C ABI (smi_fri_verify, csrc/verify.hip) against the oracle's op-for-op
+restatement of src/fri.rs:313-504 -- same verdict, same polynomial_values, on the reference's own four
+accept cases (src/fri.rs:533-693), on larger proofs, and on hundreds of tampered proofs (every kind of
+object: roots, last codeword, triples, paths, tags, lengths, truncation); and the verifier of the
+build-defined composition (smi_stark_verify) with and without column openings.  `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+P, G = 998244353, 3
+P2, G2 = 469762049, 3
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import stark_rs_amd as s
+    e = s.Engine(P, G, 0)
+    yield e
+    e.close()
+
+
+def _proof(o, n, exp, t, offset, seed, p=P, g=G):
+    omega = o.ff_prim_nth_root_g(n, p, g)
+    cw = o.fast_coset_ntt(o.splitmix64(seed, n // exp) % np.uint64(p), n, omega, offset, p)
+    cfg = o.fri_cfg(omega, offset, n, exp, t, p)
+    proof, _top = o.fri_prove(cfg, cw)
+    return omega, cfg, proof
+
+
+def _agree(o, eng, ocfg, ecfg, proof):
+    """same verdict and values as the oracle; a reference panic must surface as an exception on both sides"""
+    try:
+        want = o.fri_verify(ocfg, proof, want_values=True)
+        panic = None
+    except Exception as e:          # the oracle raises on a reference panic
+        want, panic = None, str(e)
+    if panic is not None:
+        with pytest.raises(Exception):
+            eng.fri_verify(ecfg, proof)
+        return "panic"
+    ok, pv, why = eng.fri_verify(ecfg, proof)
+    assert ok == want[0], (why, o.fri_last_reject())
+    assert pv == want[1]
+    if not ok:
+        assert why == o.fri_last_reject()
+    return ok
+
+
+@pytest.mark.parametrize("n,exp,t,offset", [(32, 4, 2, 3), (64, 4, 3, 7), (128, 4, 4, 13), (256, 8, 5, 17), (1 << 14, 8, 16, 3)])
+def test_fri_verify_accepts_what_the_reference_accepts(eng, oracle, n, exp, t, offset):
+    o = oracle
+    omega, ocfg, proof = _proof(o, n, exp, t, offset, 11 + n)
+    ecfg = eng.fri_cfg(omega, offset, n, exp, t)
+    assert _agree(o, eng, ocfg, ecfg, proof) is True
+    # the proof the device prover writes is the same bytes, so it is accepted as well
+    cw = o.fast_coset_ntt(o.splitmix64(11 + n, n // exp) % np.uint64(P), n, omega, offset)
+    got, _ = eng.fri_prove(ecfg, cw)
+    assert bytes(got) == proof
+
+
+def test_fri_verify_rejects_exactly_what_the_reference_rejects(eng, oracle):
+    o = oracle
+    n, exp, t, offset = 256, 8, 5, 17
+    omega, ocfg, proof = _proof(o, n, exp, t, offset, 5)
+    ecfg = eng.fri_cfg(omega, offset, n, exp, t)
+    rng = np.random.default_rng(7)
+    verdicts = {True: 0, False: 0, "panic": 0}
+    # single byte flips at random positions (roots, values, digests, tags, length fields)
+    for pos in rng.choice(len(proof), size=160, replace=False):
+        bad = bytearray(proof)
+        bad[pos] ^= 1 << int(rng.integers(0, 8))
+        verdicts[_agree(o, eng, ocfg, ecfg, bytes(bad))] += 1
+    # truncations and an appended tail
+    for cut in (0, 1, 33, 34, 33 * 4 + 5, len(proof) // 2, len(proof) - 1):
+        verdicts[_agree(o, eng, ocfg, ecfg, proof[:cut])] += 1
+    verdicts[_agree(o, eng, ocfg, ecfg, proof + b"\x07")] += 1
+    # an unreduced value in a triple (value + p): the arithmetic is mod p, the leaf hash is of the raw bytes
+    objs_off = 33 * o.fri_num_rounds(ocfg) + 9 + 8 * (n >> (o.fri_num_rounds(ocfg) - 1))
+    bad = bytearray(proof)
+    v = int.from_bytes(bad[objs_off + 9:objs_off + 17], "little") + P
+    bad[objs_off + 9:objs_off + 17] = v.to_bytes(8, "little")
+    verdicts[_agree(o, eng, ocfg, ecfg, bytes(bad))] += 1
+    assert verdicts[False] > 100 and verdicts[True] >= 1        # appending a byte with an unknown tag changes nothing
+
+
+def test_fri_verify_wrong_parameters(eng, oracle):
+    o = oracle
+    n, exp, t, offset = 128, 4, 4, 13
+    omega, ocfg, proof = _proof(o, n, exp, t, offset, 9)
+    # another offset / expansion factor / test count: rejected like the reference rejects it
+    for off2, exp2, t2 in ((offset + 1, exp, t), (offset, 8, t), (offset, exp, t + 1)):
+        assert _agree(o, eng, o.fri_cfg(omega, off2, n, exp2, t2), eng.fri_cfg(omega, off2, n, exp2, t2), proof) is False
+
+
+@pytest.mark.parametrize("which", ["ref_prime", "second_prime"])
+def test_stark_verify(oracle, which):
+    import stark_rs_amd as s
+    o = oracle
+    p, g = (P, G) if which == "ref_prime" else (P2, G2)
+    e = s.Engine(p, g, 0)
+    logn, lb, W, t = 10, 3, 4, 8
+    n = 1 << logn
+    cols = np.stack([o.splitmix64(0x5354524B00 + c, n) % np.uint64(p) for c in range(W)])
+    d = e.dev_alloc(W * n * 4)
+    e.dev_upload(cols.reshape(-1), d)
+    for open_columns in (False, True):
+        res = e.dev_stark_prove(d, W, logn, lb, t, open_columns=open_columns)
+        roots = [bytes(r) for r in res["column_roots"]]
+        ok, why = e.stark_verify(res["proof"], roots, W, logn, lb, t, open_columns=open_columns)
+        assert ok, why
+        bad = bytearray(res["proof"])
+        bad[len(bad) // 3] ^= 4
+        assert not e.stark_verify(bytes(bad), roots, W, logn, lb, t, open_columns=open_columns)[0]
+        if open_columns:
+            bad = bytearray(res["proof"])
+            bad[-5] ^= 1                                                   # inside the last authentication path
+            assert not e.stark_verify(bytes(bad), roots, W, logn, lb, t, open_columns=True)[0]
+            assert not e.stark_verify(res["proof"], roots[1:] + roots[:1], W, logn, lb, t, open_columns=True)[0]
+            assert not e.stark_verify(res["proof"][:-1], roots, W, logn, lb, t, open_columns=True)[0]
+    e.dev_free(d)
+    e.close()

@@ -205,3 +205,34 @@ def test_native_loop_sharded_ntt_on_the_pass_pipeline(oracle, world, logn, inver
     """smi_mgpu_ntt's loop: pass 0 on column strips, ONE all-to-all, the remaining passes -- equals the
     single transform (Polynomial::eval_domain / interpolate_domain on a geometric domain)."""
     _run(_ntt_worker, world, (logn, inverse, offset, p, g))
+
+
+def test_native_loop_statuses_mirror_the_reference_asserts(oracle):
+    """world size 1 (no collective is reached): the loop's argument checks return the status codes of the
+    reference's asserts (src/fri.rs:37-45, 183-192, 256-260) before touching any data."""
+    from stark_rs_amd.mgpu import CollOps, ALL_GATHER, EXCHANGE, ALL_REDUCE
+    from stark_rs_amd._lib import FriCfg
+    L = _emu()
+    ops = CollOps(None, ALL_GATHER(lambda *a: 1), EXCHANGE(lambda *a: 1), ALL_REDUCE(lambda *a: 1))
+    o = oracle
+    n = 256
+    omega = o.ff_prim_nth_root(n)
+    block = np.zeros(n, dtype=np.uint32)
+    proof = (C.c_uint8 * (1 << 16))()
+    plen = C.c_size_t()
+
+    def run(cfg, blk_len, rank=0, world=1, do_query=1):
+        return L.emu_mgpu_fri_prove(P, G, C.byref(ops), rank, world, C.byref(cfg), block.ctypes.data_as(u32p), blk_len, 64, do_query,
+                                    proof, len(proof), C.byref(plen), None, None)
+
+    assert run(FriCfg(omega, 3, n, 8, 5), n) == 0
+    assert run(FriCfg(omega, 3, n, 8, 5), n // 2) == -11            # initial codeword length does not match domain length
+    assert run(FriCfg(omega, 3, 200, 8, 5), 200) == -8              # Domain length must be power of 2
+    assert run(FriCfg(omega, 3, n, 6, 5), n) == -9                  # Expansion factor must be power of 2
+    assert run(FriCfg(omega, 3, n, 2, 5), n) == -10                 # Expansion factor must be at least 4
+    assert run(FriCfg(omega, 3, n, 8, 5), n, rank=0, world=3) == -50   # world sizes are powers of two
+    assert run(FriCfg(omega, 3, n, 8, 5), n, rank=2, world=2) == -50
+    assert run(FriCfg(omega, 3, 8, 8, 5), 8) == -17                 # num_rounds() == 0
+    assert run(FriCfg(P, 3, n, 8, 5), n) == -51                     # omega must be canonical
+    # (the sampling asserts of src/fri.rs:183-192 cannot fire from prove: the last codeword always has more
+    # than 4 * num_colinearity_tests elements when there is at least one round, src/fri.rs:93-103)
