@@ -77,8 +77,14 @@ def test_interpolate_known_polynomials(m, field):
         assert got == poly                                          # equality ignores trailing zeros (mod.rs:13-39)
         assert len(got.coeffs) == 4
         assert [c.value for c in got.coeffs[:len(coeffs)]] == coeffs
-    # all-zero values: the reference returns the empty polynomial (H8)
+    # all-zero values: the reference returns the empty polynomial (H8) ...
     assert m.Polynomial.interpolate_domain(domain, fe(f, 0, 0, 0, 0)).coeffs == []
+    # ... except on a one-point domain, where the single Lagrange term survives Polynomial::add's
+    # trimming: interpolate_domain([x], [0]) is [0], not [] (interpolate.rs:21-42 with add.rs:7-12) -- and a
+    # one-point domain with a non-zero value gives that constant
+    one = m.Polynomial.interpolate_domain(fe(f, 3), fe(f, 0))
+    assert [c.value for c in one.coeffs] == [0]
+    assert [c.value for c in m.Polynomial.interpolate_domain(fe(f, 3), fe(f, 7)).coeffs] == [7]
     with pytest.raises(m.PANIC, match="no inverse"):               # duplicate points (mod.rs:613-625)
         m.Polynomial.interpolate_domain(fe(f, 5, 5, 5, 5), fe(f, 1, 2, 3, 4))
     with pytest.raises(m.PANIC, match="not offset"):               # outside the fast-path contract
