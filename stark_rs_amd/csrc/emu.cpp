@@ -214,6 +214,8 @@ template <int CAP> void emu_lde_b(const LdeArgs &a) {
 }
 // coef: batch columns of 2^L coefficients (stride 2^L); out: batch columns of 2^(L+beta) evaluations
 // on the subgroup of that order (offset 1: the coset shift is applied to the coefficients upstream)
+static int g_emu_lde_geo = -1, g_emu_lde_lay = -1;
+extern "C" void emu_lde2_knobs(int geo_rq, int lay_kq) { g_emu_lde_geo = geo_rq; g_emu_lde_lay = lay_kq; }
 extern "C" int emu_lde2(uint64_t p, uint64_t g, const uint32_t *coef, uint32_t *out, uint32_t L, uint32_t beta, uint32_t batch) {
     FieldSetup fs;
     if (!field_setup(p, g, &fs) || L + beta > fs.K || !lde2_supported(L, beta)) return -1;
@@ -230,6 +232,8 @@ extern "C" int emu_lde2(uint64_t p, uint64_t g, const uint32_t *coef, uint32_t *
     a.coef = coef; a.mid = mid.data(); a.coef_t = coef_t.data(); a.ctab = (const Tw2 *)ctab.data(); a.out = out; a.coef_stride = 1ull << L; a.out_stride = 1ull << (L + beta);
     a.F = F; a.T = NttTables{(const Tw2 *)tw10.data(), lo.data(), hi.data(), fs.K, ntt_table_h(fs.K)};
     a.L = L; a.beta = beta; a.batch = batch;
+    a.geo_rq = g_emu_lde_geo >= 0 && (uint32_t)g_emu_lde_geo <= beta ? (uint32_t)g_emu_lde_geo : lde_default_geo_rq(beta);
+    a.lay_kq = g_emu_lde_lay >= (int)(SMI_LDE_BLINES_LOG - a.geo_rq) && g_emu_lde_lay <= 4 ? (uint32_t)g_emu_lde_lay : SMI_LDE_BLINES_LOG - a.geo_rq;
     const bool wide = F.p < (1u << 29);
     const int logr = (int)L - SMI_LDE_LOGB;
     {

@@ -49,6 +49,8 @@ struct LdeArgs {
     uint32_t L, beta;
     uint32_t n_tiles;       // grid.x of the launch this struct goes to
     uint32_t batch;         // grid.y
+    uint32_t lay_kq;        // the intermediate keeps 2^lay_kq adjacent k1 together: [k1 >> lay_kq][r][j0 >> 2][k1 & (2^lay_kq - 1)][j0 & 3]
+    uint32_t geo_rq;        // a tile of pass B holds 2^geo_rq cosets x 2^(4 - geo_rq) adjacent k1 (geo_rq <= beta, 4 - geo_rq <= lay_kq)
     uint32_t dbg;           // tuning runs only (SMI_LDE_DBG): 1 = pass A computes but does not store, 2 = same for pass B
 };
 
@@ -202,8 +204,8 @@ template <int LOGR, int CAP> struct LdeA {
             // (the inter-pass twiddle Omega^(j0 (r + 2^beta k1)) is applied by pass B as it reads: B is bound by
             // memory and has the issue slots, this pass is bound by arithmetic)
             const uint32_t k1b = d0 | (d1 << 4);
-            // [k1 >> kq][r][jt][k1 & (2^kq - 1)][w]; kk only moves k1 >> kq
-            const uint32_t kq = lde_kq_bits(a.beta);
+            // [k1 >> kq][r][jt][k1 & (2^kq - 1)][w]; kk only moves k1 >> kq (kq <= 4 + S1)
+            const uint32_t kq = a.lay_kq;
             const uint32_t o0 = ((((k1b >> kq) << a.beta) + t.r) << (10 + kq)) + (t.jt << (kq + 2)) + ((k1b & ((1u << kq) - 1u)) << 2) + w;
 #pragma unroll
             for (int kk = 0; kk < RL; kk++) {
@@ -230,7 +232,7 @@ template <int LOGR> struct LdeAProbe {
             const uint32_t u = tid + bi * A::NT;
             const uint32_t w = u & 3u, d0 = (u >> 2) & 15u, d1 = u >> 6, k1b = d0 | (d1 << 4);
             // tuning knob (SMI_LDE_DBG bits 16..23): store pieces of 2^(kq+4) bytes, kq = knob - 1 (0: the kernel's own)
-            const uint32_t knob = (a.dbg >> 16) & 255u, kq = knob ? knob - 1u : lde_kq_bits(a.beta);
+            const uint32_t knob = (a.dbg >> 16) & 255u, kq = knob ? knob - 1u : a.lay_kq;
             const uint32_t o0 = ((((k1b >> kq) << a.beta) + t.r) << (10 + kq)) + (t.jt << (kq + 2)) + ((k1b & ((1u << kq) - 1u)) << 2) + w;
 #pragma unroll
             for (int kk = 0; kk < A::RL; kk++) st32(mid, o0 + ((uint32_t)kk << (14 + St::s1 + a.beta)), v[bi * A::RL + kk] + 1u);
@@ -247,18 +249,18 @@ template <int CAP> struct LdeB {
     struct Geo {   // how the 16 lines split into cosets and adjacent k1 (wave-uniform)
         uint32_t rq_bits, kq_bits, rh_bits;
     };
-    static SMI_HD Geo geo(uint32_t beta) {
+    static SMI_HD Geo geo(const LdeArgs &a) {
         Geo g;
-        g.kq_bits = lde_kq_bits(beta);
-        g.rq_bits = SMI_LDE_BLINES_LOG - g.kq_bits;
-        g.rh_bits = beta - g.rq_bits;
+        g.rq_bits = a.geo_rq;
+        g.kq_bits = SMI_LDE_BLINES_LOG - g.rq_bits;
+        g.rh_bits = a.beta - g.rq_bits;
         return g;
     }
     struct TileId {
         uint32_t k1_hi, rh;   // k1 >> kq, r >> rq
     };
     static SMI_HD TileId tile_id(const LdeArgs &a, uint32_t block) {
-        const Geo g = geo(a.beta);
+        const Geo g = geo(a);
         const uint32_t t = xcd_tile(block, a.n_tiles);
         TileId id;   // the tiles that share 128-byte output lines are neighbours in tile order
         id.rh = t & ((1u << g.rh_bits) - 1u);
@@ -270,16 +272,22 @@ template <int CAP> struct LdeB {
         pa.T = a.T;
         NP::load_tw(pa, tw, tid);
     }
-    // The tile's 16 K inputs are one contiguous run [rq][jt][k1q][j0 & 3] of the intermediate.
+    // Element e of the tile = (rq, jt, k1q, j0 & 3) in that order; with lay_kq == kq_bits the tile's 16 K inputs
+    // are one contiguous run of the intermediate, with a wider layout they are 2^(kq+4)-byte pieces of its
+    // 2^(lay_kq+4)-byte blocks (the other pieces belong to the neighbouring tiles).
+    static SMI_HD uint32_t in_addr(const LdeArgs &a, const Geo &g, const TileId &t, uint32_t e) {
+        const uint32_t rq = e >> (10 + g.kq_bits), jt = (e >> (g.kq_bits + 2)) & 255u, k1q = (e >> 2) & ((1u << g.kq_bits) - 1u), j0lo = e & 3u;
+        const uint32_t k1 = (t.k1_hi << g.kq_bits) | k1q, r = (t.rh << g.rq_bits) | rq;
+        return ((((k1 >> a.lay_kq) << a.beta) + r) << (10 + a.lay_kq)) + (jt << (a.lay_kq + 2)) + ((k1 & ((1u << a.lay_kq) - 1u)) << 2) + j0lo;
+    }
     static SMI_HD void load(const LdeArgs &a, const TileId &t, uint32_t batch, uint32_t (&v)[V], uint32_t tid) {
-        const Geo g = geo(a.beta);
+        const Geo g = geo(a);
         const uint32_t *mid = a.mid + ((uint64_t)batch << (a.L + a.beta));
-        const uint32_t base = ((t.k1_hi << a.beta) + (t.rh << g.rq_bits)) << (10 + g.kq_bits);
 #pragma unroll
-        for (int i = 0; i < V; i++) v[i] = ld32(mid, base + (uint32_t)(i * NT) + tid);
+        for (int i = 0; i < V; i++) v[i] = ld32(mid, in_addr(a, g, t, (uint32_t)(i * NT) + tid));
     }
     static SMI_HD void to_lds(const LdeArgs &a, const uint32_t (&v)[V], uint32_t *tile, uint32_t tid) {
-        const Geo g = geo(a.beta);
+        const Geo g = geo(a);
 #pragma unroll
         for (int i = 0; i < V; i++) {
             const uint32_t e = (uint32_t)(i * NT) + tid;
@@ -291,7 +299,7 @@ template <int CAP> struct LdeB {
     // Omega^(j0 E), E = r + 2^beta k1 of the line, applied to the inputs as they come out of LDS: along a
     // thread's 16 rows it is a geometric sequence, so one running product.
     static SMI_HD void step0(const LdeArgs &a, const TileId &t, uint32_t *tile, const Tw2 *tw, uint32_t tid) {
-        const Geo g = geo(a.beta);
+        const Geo g = geo(a);
         const uint32_t l = tid & (W - 1), pos = tid >> SMI_LDE_BLINES_LOG;          // pos < 64
         const uint32_t r = (t.rh << g.rq_bits) | (l >> g.kq_bits), k1 = (t.k1_hi << g.kq_bits) | (l & ((1u << g.kq_bits) - 1u));
         const uint32_t E = r + (k1 << a.beta), sh = a.T.K - (a.L + a.beta);
@@ -322,7 +330,7 @@ template <int CAP> struct LdeB {
     }
     static SMI_HD void last_step_store(const LdeArgs &a, const TileId &t, uint32_t batch, const uint32_t *tile, const Tw2 *tw,
                                        uint32_t tid) {
-        const Geo g = geo(a.beta);
+        const Geo g = geo(a);
         uint32_t *out = a.out + (uint64_t)batch * a.out_stride;
         const uint32_t logRA = a.L - SMI_LDE_LOGB, ksh = a.beta + logRA;   // output index = r + 2^beta (k1 + R_A k0)
         const uint32_t base = ((t.k1_hi << g.kq_bits) << a.beta) + (t.rh << g.rq_bits);
@@ -359,7 +367,7 @@ struct LdeBProbe {
     //   4 the kernel's pattern without xcd_tile     5 whole 128-byte output lines (half as many rows, 8 bytes per lane)
     static SMI_HD void run(const LdeArgs &a, uint32_t block, uint32_t batch, uint32_t tid) {
         const uint32_t var = (a.dbg >> 8) & 255u;
-        B::Geo g = B::geo(a.beta);
+        B::Geo g = B::geo(a);
         if (var == 1 && a.beta >= 3) { g.rq_bits = 3; g.kq_bits = 1; g.rh_bits = a.beta - 3; }
         if (var == 2) { g.rq_bits = 1; g.kq_bits = 3; g.rh_bits = a.beta - 1; }
         const uint32_t *mid = a.mid + ((uint64_t)batch << (a.L + a.beta));
@@ -373,9 +381,8 @@ struct LdeBProbe {
             id.rh = t & ((1u << g.rh_bits) - 1u);
             id.k1_hi = t >> g.rh_bits;
             uint32_t v[16];
-            const uint32_t base_in = ((id.k1_hi << a.beta) + (id.rh << g.rq_bits)) << (10 + g.kq_bits);
 #pragma unroll
-            for (int i = 0; i < 16; i++) v[i] = ld32(mid, base_in + (uint32_t)(i * B::NT) + tid);
+            for (int i = 0; i < 16; i++) v[i] = ld32(mid, B::in_addr(a, g, id, (uint32_t)(i * B::NT) + tid));
             const uint32_t base = ((id.k1_hi << g.kq_bits) << a.beta) + (id.rh << g.rq_bits);
             if (var == 5) {   // lane pairs write 8 bytes each: 16 lanes cover one whole 128-byte line of one row
                 const uint32_t l = tid & 15u, row0 = tid >> 4;
@@ -401,6 +408,9 @@ struct LdeBProbe {
     }
 };
 
+// Defaults of the layout / tile geometry (overridden by SMI_LDE_LAYOUT = lay_kq, SMI_LDE_GEO = geo_rq in tuning
+// runs): measured in DESIGN.md section 3.
+SMI_HD uint32_t lde_default_geo_rq(uint32_t beta) { return beta < 2 ? beta : 2u; }
 // Which (log n, log blowup) the two-pass extension serves: lines of pass A are 2^(L-10) points
 // (1024, 2048 or 4096), at least two cosets, and the tile counts are multiples of 8 (XCD order).
 inline bool lde2_supported(uint32_t L, uint32_t beta) { return L >= 20 && L <= 22 && beta >= 1 && beta <= 4; }

@@ -280,7 +280,10 @@ int dev_lde2(smi_ctx *ctx, const uint32_t *d_coef, uint32_t *d_out, uint32_t log
     const bool wide = a.F.p < (1u << 29);
     const double n = (double)(1ull << log_n), N = (double)(1ull << logN);
     static const uint32_t dbg = getenv("SMI_LDE_DBG") ? (uint32_t)atoi(getenv("SMI_LDE_DBG")) : 0u;   // tuning runs only
+    static const int env_geo = getenv("SMI_LDE_GEO") ? atoi(getenv("SMI_LDE_GEO")) : -1, env_lay = getenv("SMI_LDE_LAYOUT") ? atoi(getenv("SMI_LDE_LAYOUT")) : -1;
     a.dbg = dbg;
+    a.geo_rq = env_geo >= 0 && (uint32_t)env_geo <= log_blowup && env_geo <= 4 ? (uint32_t)env_geo : lde_default_geo_rq(log_blowup);
+    a.lay_kq = env_lay >= (int)(SMI_LDE_BLINES_LOG - a.geo_rq) && env_lay <= 4 ? (uint32_t)env_lay : SMI_LDE_BLINES_LOG - a.geo_rq;
     const int logr = (int)log_n - SMI_LDE_LOGB;
     {
         ProfScope ps(ctx, "lde_coef_tile_kernel", 8.0 * n * batch);

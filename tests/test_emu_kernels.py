@@ -245,3 +245,19 @@ def test_emulated_ntt_deferred_first_twiddle(emu, oracle):
             assert np.array_equal(got[0], o.fast_intt(a, w, 1, p)) and np.array_equal(got[1], o.fast_intt(b, w, 1, p))
     finally:
         emu.emu_set_defer_tw(0)
+
+
+@pytest.mark.parametrize("geo,lay", [(2, 3), (2, 4), (3, 1), (3, 3), (1, 3), (1, 4)])
+def test_emulated_two_pass_lde_layout_and_tile_geometry_knobs(emu, oracle, geo, lay):
+    """the intermediate's block size (lay_kq) and pass B's split of its 16 lines into cosets x adjacent k1
+    (geo_rq) are independent tuning knobs (SMI_LDE_LAYOUT / SMI_LDE_GEO): every combination is the same map"""
+    o = oracle
+    L, beta = 20, 3
+    n, N = 1 << L, 1 << (L + beta)
+    W = o.ff_prim_nth_root_g(N, P2, G2)
+    coef = o.splitmix64(77, n) % np.uint64(P2)
+    emu.emu_lde2_knobs(geo, lay)
+    try:
+        assert np.array_equal(_lde2(emu, P2, G2, coef, L, beta), o.fast_coset_ntt(coef, N, W, 1, P2))
+    finally:
+        emu.emu_lde2_knobs(-1, -1)
