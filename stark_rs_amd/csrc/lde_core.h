@@ -280,20 +280,25 @@ template <int CAP> struct LdeB {
         const uint32_t k1 = (t.k1_hi << g.kq_bits) | k1q, r = (t.rh << g.rq_bits) | rq;
         return ((((k1 >> a.lay_kq) << a.beta) + r) << (10 + a.lay_kq)) + (jt << (a.lay_kq + 2)) + ((k1 & ((1u << a.lay_kq) - 1u)) << 2) + j0lo;
     }
+    // With e = i * 1024 + tid, the thread's bits give j0 & 3, k1q and the low 8 - kq bits of jt, the load index i
+    // the top kq bits of jt and rq: both addresses are a per-thread base plus wave-uniform multiples of two
+    // strides -- one vector add per load instead of re-deriving the fields.
     static SMI_HD void load(const LdeArgs &a, const TileId &t, uint32_t batch, uint32_t (&v)[V], uint32_t tid) {
+        static_assert(NT == 1024 && V == 16, "thread / load-index split of the tile's 14 element bits");
         const Geo g = geo(a);
         const uint32_t *mid = a.mid + ((uint64_t)batch << (a.L + a.beta));
+        const uint32_t base = in_addr(a, g, t, tid);
+        const uint32_t jt_stride = (256u >> g.kq_bits) << (a.lay_kq + 2), r_stride = 1u << (10 + a.lay_kq), imask = (1u << g.kq_bits) - 1u;
 #pragma unroll
-        for (int i = 0; i < V; i++) v[i] = ld32(mid, in_addr(a, g, t, (uint32_t)(i * NT) + tid));
+        for (int i = 0; i < V; i++) v[i] = ld32(mid, base + ((uint32_t)i & imask) * jt_stride + ((uint32_t)i >> g.kq_bits) * r_stride);
     }
     static SMI_HD void to_lds(const LdeArgs &a, const uint32_t (&v)[V], uint32_t *tile, uint32_t tid) {
         const Geo g = geo(a);
+        const uint32_t k1q = (tid >> 2) & ((1u << g.kq_bits) - 1u), j0lo = tid & 3u, jt_lo = tid >> (g.kq_bits + 2);
+        const uint32_t base = ((jt_lo << 2) + j0lo) * WP + k1q;
+        const uint32_t jt_stride = (256u >> g.kq_bits) * 4u * WP, r_stride = 1u << g.kq_bits, imask = (1u << g.kq_bits) - 1u;
 #pragma unroll
-        for (int i = 0; i < V; i++) {
-            const uint32_t e = (uint32_t)(i * NT) + tid;
-            const uint32_t rq = e >> (10 + g.kq_bits), jt = (e >> (g.kq_bits + 2)) & 255u, k1q = (e >> 2) & ((1u << g.kq_bits) - 1u), j0lo = e & 3u;
-            tile[((jt << 2) + j0lo) * WP + ((rq << g.kq_bits) | k1q)] = v[i];
-        }
+        for (int i = 0; i < V; i++) tile[base + ((uint32_t)i & imask) * jt_stride + ((uint32_t)i >> g.kq_bits) * r_stride] = v[i];
     }
     // First in-tile step (radix 16 over rows pos + 64 q of line l), with the inter-pass twiddle
     // Omega^(j0 E), E = r + 2^beta k1 of the line, applied to the inputs as they come out of LDS: along a

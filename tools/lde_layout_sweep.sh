@@ -1,6 +1,7 @@
 #!/bin/bash
-# Development tool: the two-pass extension for every (pass-B tile geometry, intermediate layout) pair, real kernels,
-# with the generic path of the same box first.
+# Development tool: the two-pass extension for (pass-B tile geometry, intermediate layout) pairs, real kernels and
+# copy-only twins (in parentheses), with the generic path of the same box first.
+#   bash tools/lde_layout_sweep.sh "2 3" "3 2" ...      (pairs "geo_rq lay_kq"; default: all valid pairs)
 run() {
   python bench.py --no-extras --steps 10 --warmup 2 2>/dev/null | python -c "
 import json,sys
@@ -10,6 +11,8 @@ print('   ms_per_step %.4f  '%r['ms_per_step'] + '  '.join('%s %.0f(%.0f)'%(n.re
 "
 }
 echo "== generic"; run
-for geo in 2 3; do for lay in 1 2 3 4; do
-  if [ $((4 - geo)) -le $lay ]; then echo "== geo_rq=$geo lay_kq=$lay"; SMI_LDE_TWO_PASS=1 SMI_LDE_GEO=$geo SMI_LDE_LAYOUT=$lay run; fi
-done; done
+if [ $# -eq 0 ]; then set -- "2 2" "2 3" "2 4" "3 1" "3 2" "3 3" "3 4"; fi
+for pair in "$@"; do
+  set -- $pair
+  echo "== geo_rq=$1 lay_kq=$2"; SMI_LDE_TWO_PASS=1 SMI_LDE_GEO=$1 SMI_LDE_LAYOUT=$2 run
+done
