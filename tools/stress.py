@@ -2,7 +2,10 @@
 """Development tool (GPU box): randomized parity sweep against the oracle for a time budget.
     python tools/stress.py [seconds]
 NTT / iNTT at random sizes, offsets and paddings on both primes, Merkle trees (element and row
-leaves), folds, FRI proofs (byte-identical to the oracle's), polynomial products and divisions."""
+leaves), folds, FRI proofs (byte-identical to the oracle's), polynomial products and divisions,
+smi_fri_verify against the oracle's verdict on tampered proofs, the whole prove with column openings
+(single-GPU and through the multi-GPU entry points at world size 1) + smi_stark_verify, and the
+two-pass extension."""
 import os
 import sys
 import time
@@ -18,14 +21,16 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     o.build()
     rng = np.random.default_rng(int(os.environ.get("SEED", "12345")))
+    from stark_rs_amd.mgpu import MultiGpu
     engs = {s.P_REF: s.Engine(s.P_REF, s.G_REF, 0), s.P2: s.Engine(s.P2, s.G2, 0)}
     gens = {s.P_REF: s.G_REF, s.P2: s.G2}
+    mgs = {p_: MultiGpu(e_, 0, 1, min_block=1 << 8) for p_, e_ in engs.items()}
     t0, n_cases = time.time(), 0
     last_note = t0
     while time.time() - t0 < budget:
         p = int(rng.choice([s.P_REF, s.P2]))
         e, g = engs[p], gens[p]
-        kind = rng.integers(0, 7)
+        kind = rng.integers(0, 10)
         if kind == 0:      # inverse transform
             L = int(rng.integers(0, 22))
             n = 1 << L
@@ -100,6 +105,66 @@ def main():
             assert got == o.merkle_commit(leaves), ("row tree", L, W)
             e.dev_free(d_cols)
             e.dev_free(d_nodes)
+        elif kind == 7 and p == s.P_REF:   # Fri::verify: same verdict, reason and values as the oracle on a tampered proof
+            L = int(rng.integers(5, 11))
+            n = 1 << L
+            tt = int(rng.integers(1, min(8, (n >> 4)) + 1))
+            w, off = o.ff_prim_nth_root(n), int(rng.integers(1, p))
+            cw = o.fast_coset_ntt(rng.integers(0, p, n >> 2, dtype=np.int64).astype(np.uint64), n, w, off)
+            cfg = o.fri_cfg(w, off, n, 4, tt)
+            if o.fri_num_rounds(cfg) == 0:
+                continue
+            proof = bytearray(o.fri_prove(cfg, cw)[0])
+            if rng.integers(0, 4):
+                proof[int(rng.integers(0, len(proof)))] ^= 1 << int(rng.integers(0, 8))
+            proof = bytes(proof[:int(rng.integers(0, len(proof)))] if rng.integers(0, 8) == 0 else proof)
+            ecfg = e.fri_cfg(w, off, n, 4, tt)
+            try:
+                want = o.fri_verify(cfg, proof, want_values=True)
+            except Exception:
+                try:
+                    e.fri_verify(ecfg, proof)
+                    raise AssertionError(("verify: the reference panics, the device verifier does not", L, tt))
+                except s.StarkMiError:
+                    pass
+            else:
+                ok, pv, why = e.fri_verify(ecfg, proof)
+                assert (ok, pv) == want and (ok or why == o.fri_last_reject()), ("verify", L, tt, why, o.fri_last_reject())
+        elif kind == 8:                    # whole prove with column openings: single GPU == multi-GPU entry points, verifier accepts
+            logn, lb, W, tt = int(rng.integers(4, 12)), int(rng.integers(2, 4)), int(rng.integers(1, 6)), int(rng.integers(1, 5))
+            n = 1 << logn
+            if (n << lb) <= max(1 << lb, 4 * tt) or logn + lb > (23 if p == s.P_REF else 26):
+                continue
+            cols = rng.integers(0, p, (W, n), dtype=np.int64).astype(np.uint64)
+            d_cols = e.dev_alloc(W * n * 4)
+            e.dev_upload(cols.reshape(-1), d_cols)
+            one = e.dev_stark_prove(d_cols, W, logn, lb, tt, open_columns=True)
+            roots, proof, top = mgs[p].stark_prove(d_cols, W, logn, lb, tt, open_columns=True)
+            assert roots == [bytes(r) for r in one["column_roots"]] and proof == one["proof"] and top == one["top_indices"], ("mgpu prove", logn, lb, W, tt)
+            ok, why = e.stark_verify(proof, roots, W, logn, lb, tt, open_columns=True)
+            assert ok, ("stark_verify", why)
+            bad = bytearray(proof)
+            bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+            try:
+                assert not e.stark_verify(bytes(bad), roots, W, logn, lb, tt, open_columns=True)[0], ("stark_verify accepted a flipped bit",)
+            except s.StarkMiError:
+                pass                       # a flipped length field can be the reference's panic
+            e.dev_free(d_cols)
+        elif kind == 9:                    # two-pass extension == generic extension
+            logn, lb, W = int(rng.integers(20, 23)), int(rng.integers(1, 4)), int(rng.integers(1, 4))
+            if logn + lb > (23 if p == s.P_REF else 25):
+                continue
+            n, N = 1 << logn, 1 << (logn + lb)
+            cols = rng.integers(0, p, (W, n), dtype=np.int64).astype(np.uint64)
+            d_cols, d_a, d_b = e.dev_alloc(W * n * 4), e.dev_alloc(W * N * 4), e.dev_alloc(W * N * 4)
+            e.dev_upload(cols.reshape(-1), d_cols)
+            e.dev_lde(d_cols, W, logn, lb, d_a, 1, g)
+            e.lde_two_pass(True)
+            e.dev_lde(d_cols, W, logn, lb, d_b, 1, g)
+            e.lde_two_pass(False)
+            assert np.array_equal(e.dev_download(d_a, W * N), e.dev_download(d_b, W * N)), ("two-pass lde", logn, lb, W)
+            for d in (d_cols, d_a, d_b):
+                e.dev_free(d)
         else:
             continue
         n_cases += 1
