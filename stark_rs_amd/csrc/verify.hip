@@ -212,35 +212,46 @@ int fri_verify_objs(smi_ctx *ctx, const smi_fri_cfg &cfg, const std::vector<Obj>
             if (mulm(subm(bb[s], aa[s], p), subm(cx, ax, p), p) != mulm(subm(cc[s], aa[s], p), subm(bx, ax, p), p))
                 return reject(ctx, accept, "colinearity check failure");
         }
-        // the 3t authentication paths: one device batch per (a, b, c); a batch shares its depth, so a path
-        // of another length is checked on its own terms (it cannot verify: MerkleTree::verify walks it all)
+        // The 3t authentication paths.  The reference pops and verifies them one at a time in the order
+        // (test 0: a, b, c), (test 1: a, b, c), ... and stops at the first failure of either kind; here the paths
+        // are verified in one device batch per (a, b, c), so the pops run first, up to the first one that fails,
+        // and the verdict is the earliest failure in the reference's order.
+        static const char *const miss[3] = {"Failed to extract path for aa", "Failed to extract path for bb", "Failed to extract path for cc"};
+        static const char *const bad[3] = {"merkle authentication path verification fails for aa", "merkle authentication path verification fails for bb",
+                                           "merkle authentication path verification fails for cc"};
         const uint32_t want_depth[3] = {ilog2(2 * half), ilog2(2 * half), ilog2(half)};
         std::vector<std::vector<uint8_t>> paths(3);
-        for (uint64_t s = 0; s < t; s++)
+        std::vector<uint64_t> have(3, 0);        // how many paths of each kind were popped
+        uint64_t stop_at = 3 * t;                // position (3 s + w) of the first pop that failed
+        const char *stop_why = nullptr;
+        for (uint64_t s = 0; s < t && !stop_why; s++)
             for (int w = 0; w < 3; w++) {
-                static const char *const miss[3] = {"Failed to extract path for aa", "Failed to extract path for bb", "Failed to extract path for cc"};
-                static const char *const bad[3] = {"merkle authentication path verification fails for aa",
-                                                   "merkle authentication path verification fails for bb",
-                                                   "merkle authentication path verification fails for cc"};
                 const Obj *o = pop();
-                if (!o || o->tag != 3) return reject(ctx, accept, miss[w]);
-                if (o->count != want_depth[w]) return reject(ctx, accept, bad[w]);   // wrong length: the recomputed root cannot match
+                if (!o || o->tag != 3) { stop_at = 3 * s + w; stop_why = miss[w]; break; }
+                if (o->count != want_depth[w]) { stop_at = 3 * s + w; stop_why = bad[w]; break; }   // wrong length: the recomputed root cannot match
                 paths[w].insert(paths[w].end(), o->p, o->p + 32 * o->count);
+                have[w]++;
             }
         const std::vector<uint64_t> *vals[3] = {&aa, &bb, &cc}, *idxs[3] = {&ci, &bi, &ci};
         const uint8_t *rt[3] = {roots[r], roots[r], roots[r + 1]};
-        static const char *const bad[3] = {"merkle authentication path verification fails for aa", "merkle authentication path verification fails for bb",
-                                           "merkle authentication path verification fails for cc"};
+        uint64_t first_bad = stop_at;
+        const char *why = stop_why;
         for (int w = 0; w < 3; w++) {
-            std::vector<uint8_t> leaf, ok(t ? t : 1);
-            SMI_TRY(leaf_digests(ctx, vals[w]->data(), t, leaf));
-            if (t && want_depth[w])
-                SMI_TRY(smi_merkle_verify_batch(ctx, leaf.data(), idxs[w]->data(), paths[w].data(), t, want_depth[w], rt[w], ok.data()));
+            const uint64_t k = have[w];
+            if (!k) continue;
+            std::vector<uint8_t> leaf, ok(k);
+            SMI_TRY(leaf_digests(ctx, vals[w]->data(), k, leaf));
+            if (want_depth[w])
+                SMI_TRY(smi_merkle_verify_batch(ctx, leaf.data(), idxs[w]->data(), paths[w].data(), k, want_depth[w], rt[w], ok.data()));
             else
-                for (uint64_t s = 0; s < t; s++) ok[s] = memcmp(&leaf[32 * s], rt[w], 32) == 0;   // a one-leaf tree: the leaf is the root
-            for (uint64_t s = 0; s < t; s++)
-                if (!ok[s]) return reject(ctx, accept, bad[w]);
+                for (uint64_t s = 0; s < k; s++) ok[s] = memcmp(&leaf[32 * s], rt[w], 32) == 0;   // a one-leaf tree: the leaf is the root
+            for (uint64_t s = 0; s < k; s++)
+                if (!ok[s] && 3 * s + w < first_bad) {
+                    first_bad = 3 * s + w;
+                    why = bad[w];
+                }
         }
+        if (why) return reject(ctx, accept, why);
         om = mulm(om, om, p);
         off = mulm(off, off, p);
     }
