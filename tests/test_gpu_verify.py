@@ -120,3 +120,24 @@ def test_stark_verify(oracle, which):
             assert not e.stark_verify(res["proof"][:-1], roots, W, logn, lb, t, open_columns=True)[0]
     e.dev_free(d)
     e.close()
+
+
+def test_fri_verify_reports_the_first_failure_in_the_reference_order(eng, oracle):
+    """two corrupted authentication paths: the reference walks (test 0: a, b, c), (test 1: a, b, c), ... and
+    stops at the first that fails; the batched verifier must name the same one (src/fri.rs:431-498)."""
+    o = oracle
+    n, exp, t, offset = 256, 8, 5, 17
+    omega, ocfg, proof = _proof(o, n, exp, t, offset, 5)
+    ecfg = eng.fri_cfg(omega, offset, n, exp, t)
+    R = o.fri_num_rounds(ocfg)
+    depth = n.bit_length() - 1
+    paths0 = 33 * R + 9 + 8 * (n >> (R - 1)) + 33 * t             # first MerklePath of layer 0
+    pa, pc = 9 + 32 * depth, 9 + 32 * (depth - 1)
+    at = lambda s, w: paths0 + s * (2 * pa + pc) + (0, pa, 2 * pa)[w] + 9 + 5     # a byte inside that path's first digest
+    for first, second in (((0, 1), (1, 0)), ((0, 2), (1, 0)), ((1, 1), (2, 0)), ((3, 0), (3, 2))):
+        bad = bytearray(proof)
+        bad[at(*first)] ^= 1
+        bad[at(*second)] ^= 1
+        ok, _pv, why = eng.fri_verify(ecfg, bytes(bad))
+        assert not ok and not o.fri_verify(ocfg, bytes(bad))
+        assert why == o.fri_last_reject() == "merkle authentication path verification fails for " + ("aa", "bb", "cc")[first[1]]
