@@ -269,20 +269,27 @@ int ctx_root_table(smi_ctx *ctx, uint32_t log_m, const Tw2 **out) {
     *out = (const Tw2 *)ctx->d_root_tab[log_m];
     return SMI_OK;
 }
+// Makes room for `n` new entries NOW, so that the next n ctx_scale_tables calls cannot evict: a caller that
+// collects several tables before its launch (the fused FRI tail) would otherwise be left holding freed ones.
+int ctx_scale_reserve(smi_ctx *ctx, size_t n) {
+    if (ctx->scale_cache.size() + n < SMI_SCALE_CACHE_MAX) return SMI_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // in-flight kernels may still read the ones dropped
+    size_t drop = ctx->scale_cache.size() / 2 > n ? ctx->scale_cache.size() / 2 : ctx->scale_cache.size();
+    if (drop > ctx->scale_cache.size()) drop = ctx->scale_cache.size();
+    for (size_t i = 0; i < drop; i++) {
+        (void)hipFree(ctx->scale_cache[i].lo);
+        (void)hipFree(ctx->scale_cache[i].hi);
+    }
+    ctx->scale_cache.erase(ctx->scale_cache.begin(), ctx->scale_cache.begin() + (long)drop);
+    return SMI_OK;
+}
 int ctx_scale_tables(smi_ctx *ctx, uint32_t c_plain, uint32_t q_plain, uint32_t L, ScaleTables *out) {
     for (const ScaleEntry &e : ctx->scale_cache)
         if (e.c == c_plain && e.q == q_plain && e.L == L) {
             *out = ScaleTables{e.lo, e.hi, scale_table_h(L)};
             return SMI_OK;
         }
-    if (ctx->scale_cache.size() >= 96) {  // drop the oldest half; in-flight kernels may still read them
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        for (size_t i = 0; i < 48; i++) {
-            (void)hipFree(ctx->scale_cache[i].lo);
-            (void)hipFree(ctx->scale_cache[i].hi);
-        }
-        ctx->scale_cache.erase(ctx->scale_cache.begin(), ctx->scale_cache.begin() + 48);
-    }
+    SMI_TRY(ctx_scale_reserve(ctx, 1));   // full: drops the oldest half (after draining the stream)
     GeomSpec sp[2];
     scale_table_specs(ctx->fs.F, c_plain, q_plain, L, sp);
     ScaleEntry e{c_plain, q_plain, L, nullptr, nullptr};

@@ -441,6 +441,8 @@ int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, si
     for (uint64_t r = 0; r < R; r++) {
         if (cur_len <= tail_len && R - r <= SMI_FRI_TAIL_MAX_ROUNDS) {
             // every remaining round in one workgroup launch (hash.hip, fri_tail_kernel)
+            // the tail holds one x^-1 table per fold until its launch: none of them may be evicted in between
+            if ((rc = ctx_scale_reserve(ctx, (size_t)(R - r))) != SMI_OK) return bail(rc);
             FriTailArgs ta;
             memset(&ta, 0, sizeof ta);
             ta.n_rounds = (uint32_t)(R - r);

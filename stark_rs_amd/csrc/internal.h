@@ -117,6 +117,8 @@ NttTables ctx_tables(const smi_ctx *ctx, int inverse);
 // device table of w_m^e, e < m = 2^log_m (forward root), as Tw2 pairs; cached per log_m (log_m <= 17)
 int ctx_root_table(smi_ctx *ctx, uint32_t log_m, const Tw2 **out);
 int ctx_scale_tables(smi_ctx *ctx, uint32_t c_plain, uint32_t q_plain, uint32_t L, ScaleTables *out);
+#define SMI_SCALE_CACHE_MAX 96
+int ctx_scale_reserve(smi_ctx *ctx, size_t n);   // room for n more entries without an eviction in between
 
 // field helpers on the host (plain form)
 inline uint32_t h_mul(const smi_ctx *c, uint32_t a, uint32_t b) { return host_mulmod(a, b, c->fs.F.p); }

@@ -534,3 +534,20 @@ def test_max_size_second_prime_2p26_sampled(eng2, oracle):
         assert o.poly_eval(coeffs, o.ff_mul(5, o.ff_exp(w, k, P2), P2), P2) == int(ev[k])
     back = eng2.intt(ev, 5)
     assert np.array_equal(back[: 1 << 16], coeffs) and not back[1 << 16:].any()
+
+
+def test_fri_prove_while_the_scale_table_cache_wraps(eng, oracle):
+    """The context caches at most 96 x^-1 / scale tables and drops the oldest half when full.  The fused FRI
+    tail (csrc/hash.hip, fri_tail_kernel) holds one table per remaining fold until its single launch, so an
+    eviction while it collects them would leave it reading freed memory (found by tools/stress.py: an
+    intermittent wrong proof).  40 proves with fresh offsets wrap the cache several times at every alignment."""
+    o = oracle
+    n, exp, t = 1 << 12, 4, 4
+    omega = o.ff_prim_nth_root(n)
+    coeffs = o.splitmix64(3, n // exp) % np.uint64(P)
+    for k in range(40):
+        offset = 3 + 2 * k
+        cw = o.fast_coset_ntt(coeffs, n, omega, offset)
+        want, wtop = o.fri_prove(o.fri_cfg(omega, offset, n, exp, t), cw)
+        got, top = eng.fri_prove(eng.fri_cfg(omega, offset, n, exp, t), cw)
+        assert bytes(got) == want and list(top) == wtop, k

@@ -72,6 +72,16 @@ def main():
     src, tag = sys.argv[1], sys.argv[2]
     dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     os.makedirs(dst, exist_ok=True)
+    if len(sys.argv) > 3 and sys.argv[3] == "prove":          # VALU instructions per wave of the prove's kernels
+        valu = counters(os.path.join(src, "prove_valu"))
+        out = {}
+        for k, v in sorted(valu.items()):
+            if v.get("SQ_INSTS_VALU") and v.get("SQ_WAVES") and sum(v["SQ_WAVES"]):
+                out[k] = {"launches_profiled": len(v["SQ_WAVES"]), "valu_insts_per_wave": sum(v["SQ_INSTS_VALU"]) / sum(v["SQ_WAVES"])}
+        json.dump({"note": "rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES over tools/kbench.py prove:22:3:4 (2^22 x 4 trace, blowup 8)", **out},
+                  open(os.path.join(dst, f"{tag}_prove_pmc.json"), "w"), indent=1)
+        print(json.dumps(out, indent=1))
+        return
     if len(sys.argv) > 3 and sys.argv[3] == "two_pass":       # the opt-in two-pass extension, SMI_LDE_TWO_PASS=1
         for path in glob.glob(os.path.join(src, "stats2", "**", "*kernel_stats.csv"), recursive=True):
             shutil.copy(path, os.path.join(dst, f"{tag}_lde_two_pass_kernel_stats.csv"))
