@@ -26,9 +26,12 @@ def bench_name(sym):
         return f"lde_a_kernel<{m.group(1)}>"
     if "lde_b_kernel" in sym:
         return "lde_b_kernel"
-    m = re.search(r"merkle_sub_kernel<(true|false)>", sym)
+    m = re.search(r"merkle_sub_kernel<(true|false)(?:, (\d+), (true|false))?>", sym)
     if m:
-        return "merkle_sub_kernel<leaves>" if m.group(1) == "true" else "merkle_sub_kernel<digests>"
+        kind = "leaves" if m.group(1) == "true" else "digests"
+        if m.group(3) == "true":
+            kind = "row leaves"
+        return f"merkle_sub_kernel<{kind}>" + (f" K={m.group(2)}" if m.group(2) and m.group(2) != "0" else "")
     m = re.search(r"(\w+_kernel)", sym)
     return m.group(1) if m else sym
 
