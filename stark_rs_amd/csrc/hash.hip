@@ -52,6 +52,44 @@ __global__ __launch_bounds__(SMI_HASH_THREADS) void merkle_sub_kernel(const uint
 #pragma unroll
         for (int w = 0; w < 8; w++) d[w] = stash[(slot * 8 + w) * SMI_HASH_THREADS + tid];
     };
+    if constexpr (KT == 2 && !ROWS) {
+        // The shape the prover lives in, written out: four inputs per lane, two levels.  Only the first
+        // pair of leaf digests waits in the stash (while the second pair is hashed); everything else goes
+        // from the registers that produced it into the hash that consumes it.
+        auto store = [&](uint4 *dst, const uint32_t (&d)[8]) {
+            dst[0] = make_uint4(d[0], d[1], d[2], d[3]);
+            dst[1] = make_uint4(d[4], d[5], d[6], d[7]);
+        };
+        uint32_t l0[8], r0[8], l1[8], r1[8];
+        if constexpr (FROM_ELEMS) {
+            {
+                uint32_t d0[8], d1[8];
+                hashc::leaf_hash2(elems[first], elems[first + 1], d0, d1);
+                put(nodes + 2 * first, 0, d0);
+                put(nodes + 2 * (first + 1), 1, d1);
+            }
+            hashc::leaf_hash2(elems[first + 2], elems[first + 3], l1, r1);
+            store(nodes + 2 * (first + 2), l1);
+            store(nodes + 2 * (first + 3), r1);
+            get(0, l0);
+            get(1, r0);
+        } else {
+            const uint4 *src = nodes + 2 * (level_offset(n, lvl_in) + first);
+            auto load = [&](int i, uint32_t (&d)[8]) {
+                const uint4 a = src[2 * i], b = src[2 * i + 1];
+                d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+            };
+            load(0, l0); load(1, r0); load(2, l1); load(3, r1);
+        }
+        uint32_t n0[8], n1[8], top[8];
+        hashc::node_hash2(l0, r0, l1, r1, n0, n1);
+        uint4 *dst1 = nodes + 2 * (level_offset(n, lvl_in + 1) + (t << 1));
+        store(dst1, n0);
+        store(dst1 + 2, n1);
+        hashc::node_hash(n0, n1, top);
+        store(nodes + 2 * (level_offset(n, lvl_in + 2) + t), top);
+        return;
+    }
     if (FROM_ELEMS && ROWS && row_cols) {
         // row leaves: leaf i = Hash::from_field_elements(row i) over row_cols <= 4 columns row_stride
         // apart (wider rows are hashed by row_hash_kernel and enter as digests)
@@ -493,12 +531,12 @@ static int launch_merkle_impl(smi_ctx *ctx, const uint32_t *d_elems, size_t n, u
         static const bool generic_only = getenv("SMI_MERKLE_GENERIC") && atoi(getenv("SMI_MERKLE_GENERIC"));
         if (from_elems && row_cols)
             merkle_sub_kernel<true, 0, true><<<grid, SMI_HASH_THREADS, lds, ctx->stream>>>(d_elems, nodes, n, 0, count, K, elem_stride, node_stride, row_cols, row_stride);
-        else if (from_elems && K == 2 && !generic_only)
-            merkle_sub_kernel<true, 2, false><<<grid, SMI_HASH_THREADS, lds, ctx->stream>>>(d_elems, nodes, n, 0, count, K, elem_stride, node_stride, 0, 0);
+        else if (from_elems && K == 2 && !generic_only)   // its stash holds two digests per lane
+            merkle_sub_kernel<true, 2, false><<<grid, SMI_HASH_THREADS, (size_t)16 * SMI_HASH_THREADS * sizeof(uint32_t), ctx->stream>>>(d_elems, nodes, n, 0, count, K, elem_stride, node_stride, 0, 0);
         else if (from_elems)
             merkle_sub_kernel<true, 0, false><<<grid, SMI_HASH_THREADS, lds, ctx->stream>>>(d_elems, nodes, n, 0, count, K, elem_stride, node_stride, 0, 0);
-        else if (K == 2 && !generic_only)
-            merkle_sub_kernel<false, 2, false><<<grid, SMI_HASH_THREADS, lds, ctx->stream>>>(nullptr, nodes, n, lvl, count, K, 0, node_stride, 0, 0);
+        else if (K == 2 && !generic_only)                 // no stash at all
+            merkle_sub_kernel<false, 2, false><<<grid, SMI_HASH_THREADS, 0, ctx->stream>>>(nullptr, nodes, n, lvl, count, K, 0, node_stride, 0, 0);
         else
             merkle_sub_kernel<false, 0, false><<<grid, SMI_HASH_THREADS, lds, ctx->stream>>>(nullptr, nodes, n, lvl, count, K, 0, node_stride, 0, 0);
         HIP_TRY(ctx, hipGetLastError());
