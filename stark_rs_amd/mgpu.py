@@ -151,9 +151,14 @@ class MultiGpu:
             check(self.L.smi_mgpu_create_with(engine.h, C.byref(host.ops), rank, world, C.byref(h)), engine.h)
         else:
             buf = (C.c_uint8 * 128)()
-            if rank == 0:
-                check(self.L.smi_mgpu_unique_id(buf), engine.h)
-            ident = carry(bytes(buf), rank) if world > 1 else bytes(buf)
+            st = self.L.smi_mgpu_unique_id(buf) if rank == 0 else 0
+            # rank 0 always takes part in the carry, so a failure there cannot leave the others waiting
+            ident = bytes(buf) if st == 0 else b""
+            if world > 1:
+                ident = carry(ident, rank)
+            check(st, engine.h)
+            if len(ident) != 128:
+                raise RuntimeError("rank 0 could not draw an RCCL unique id")
             buf = (C.c_uint8 * 128).from_buffer_copy(ident)
             check(self.L.smi_mgpu_create(engine.h, buf, rank, world, C.byref(h)), engine.h)
         self.h = h
