@@ -24,9 +24,45 @@ std::vector<uint32_t> fill(const GeomSpec &s, const Fp &F) {
     return t;
 }
 
+// ntt_pass_cols_kernel: every column of a tile by one workgroup, output multipliers derived once per thread
+template <int LOGR, int LOGW, int KIND, int CAP> void emu_pass_cols(const PassArgs &a) {
+    typedef NttPass<LOGR, LOGW, KIND, CAP> NP;
+    constexpr bool LAST = KIND == PASS_LAST;
+    const uint32_t NT = NP::NT;
+    std::vector<uint32_t> tile(NP::R * NP::WP);
+    std::vector<Tw2> tw(NP::R);
+    std::vector<std::array<uint32_t, 16>> mw(NT), mq(NT), regs(NT);
+    auto r16 = [](std::array<uint32_t, 16> &x) -> uint32_t(&)[16] { return reinterpret_cast<uint32_t(&)[16]>(x); };
+    for (uint32_t blk = 0; blk < a.n_tiles; blk++) {
+        typename NP::TileId t = NP::tile_id(a, blk);
+        for (uint32_t tid = 0; tid < NT; tid++) NP::load_tw(a, tw.data(), tid);
+        for (uint32_t tid = 0; tid < NT; tid++) NP::out_mul(a, t, tid, r16(mw[tid]), r16(mq[tid]));
+        for (uint32_t b = 0; b < a.batch; b++) {
+            if (!LAST) {
+#define ZCASE(Z)                                                                                                 \
+    case Z:                                                                                                      \
+        for (uint32_t tid = 0; tid < NT; tid++) NP::template load_regs<Z>(a, t, b, r16(regs[tid]), tid);         \
+        for (uint32_t tid = 0; tid < NT; tid++) NP::template step0_regs<Z>(a, r16(regs[tid]), tile.data(), tw.data(), tid); \
+        break;
+                switch (a.zlog) { ZCASE(2) ZCASE(3) ZCASE(4) default: ZCASE(0) }
+#undef ZCASE
+            } else {
+                for (uint32_t tid = 0; tid < NT; tid++) NP::load_rows(a, t, b, r16(regs[tid]), tid);
+                for (uint32_t tid = 0; tid < NT; tid++) NP::rows_to_lds(r16(regs[tid]), tile.data(), tid);
+                for (uint32_t tid = 0; tid < NT; tid++) NP::step0_lds(a, tile.data(), tw.data(), tid);
+            }
+            for (uint32_t tid = 0; tid < NT; tid++) NP::step_mid(a, tile.data(), tw.data(), tid);
+            for (uint32_t tid = 0; tid < NT; tid++) NP::last_step_store_mul(a, t, b, tile.data(), tw.data(), tid, r16(mw[tid]), r16(mq[tid]));
+        }
+    }
+}
+
+bool g_share_cols = true;   // emu_set_share_cols: the launcher's choice (HipLauncher::launch), switchable for the tests
+
 template <int LOGR, int LOGW, int KIND, int CAP> void emu_pass(const PassArgs &a, uint32_t batch) {
     typedef NttPass<LOGR, LOGW, KIND, CAP> NP;
     constexpr bool LAST = KIND == PASS_LAST;
+    if (g_share_cols && NP::share_cols(a)) return emu_pass_cols<LOGR, LOGW, KIND, CAP>(a);
     std::vector<uint32_t> tile(NP::R * NP::WP);
     std::vector<Tw2> tw(NP::R);
     for (uint32_t b = 0; b < batch; b++)
@@ -93,6 +129,7 @@ struct EmuLauncher {
 
 static bool g_emu_defer_tw = false;
 extern "C" void emu_set_defer_tw(int on) { g_emu_defer_tw = on != 0; }
+extern "C" void emu_set_share_cols(int on) { g_share_cols = on != 0; }
 extern "C" int emu_ntt(uint64_t p, uint64_t g, const uint32_t *in, uint32_t *out, uint32_t L, uint32_t n_in,
                        uint32_t batch, uint64_t in_stride, uint64_t out_stride, int inverse, uint64_t offset,
                        uint64_t post_scale) {

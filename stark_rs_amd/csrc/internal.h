@@ -41,6 +41,7 @@ struct smi_ctx {
     bool prof_on = false;
     bool copy_probe = false;       // smi_ctx_copy_probe: NTT passes launch their copy-only twins
     // three-pass transforms: the second pass applies the first pass's inter-pass twiddle as it loads (ntt_core.h)
+    bool ntt_share_cols = !(getenv("SMI_NTT_SHARE_COLS") && atoi(getenv("SMI_NTT_SHARE_COLS")) == 0);   // tuning knob, default on
     bool ntt_defer_tw = !(getenv("SMI_NTT_DEFER_TW") && atoi(getenv("SMI_NTT_DEFER_TW")) == 0) && getenv("SMI_NTT_DEFER_TW") != nullptr;
     bool lde_two_pass = getenv("SMI_LDE_TWO_PASS") && atoi(getenv("SMI_LDE_TWO_PASS"));   // smi_ctx_lde_two_pass
     std::vector<ProfRec> prof;

@@ -51,6 +51,61 @@ __global__ __launch_bounds__(1 << (LOGR + LOGW - 4)) void ntt_pass_kernel(const 
     NP::last_step_store(a, t, batch, tile, tw, tid);
 }
 
+// The same tile program with every column of the tile taken by one workgroup (grid.y = 1): the output multipliers
+// of a thread are derived once and applied to all a.batch columns (NttPass::out_mul).  The launcher picks it when
+// there is more than one column and the pass has output multipliers.
+// Waves per SIMD the register allocation must leave room for, by log2 of the tile (tools/exp_share_cols.sh, 2^25 x 4
+// middle pass): unbounded 81 VGPRs 229 us, 6 waves (73 VGPRs) 222 us, 8 waves (64 VGPRs, 8 spilled) 254 us; one
+// workgroup per (tile, column) 237 us.
+#ifndef SMI_COLS_WAVES
+#define SMI_COLS_WAVES(TILE_LOG) ((TILE_LOG) >= 14 ? 4 : 6)
+#endif
+template <int LOGR, int LOGW, int KIND, int CAP>
+__global__ __launch_bounds__(1 << (LOGR + LOGW - 4), SMI_COLS_WAVES(LOGR + LOGW)) void ntt_pass_cols_kernel(const PassArgs a) {
+    typedef NttPass<LOGR, LOGW, KIND, CAP> NP;
+    __shared__ uint32_t tile[NP::R * NP::WP];
+    __shared__ Tw2 tw[NP::R];
+    const uint32_t tid0 = threadIdx.x;
+    const typename NP::TileId t = NP::tile_id(a, blockIdx.x);
+    NP::load_tw(a, tw, tid0);
+    uint32_t mw[NP::V], mq[NP::V];
+    NP::out_mul(a, t, tid0, mw, mq);
+    for (uint32_t batch = 0; batch < a.batch; batch++) {
+        // Opaque per-iteration copy of the thread index: without it every address of the tile program (loop-invariant
+        // across the columns) is hoisted and held in registers -- 150 VGPRs, or spills under a bound
+        uint32_t tid = tid0;
+        asm volatile("" : "+v"(tid));
+        uint32_t v[NP::V];
+        // the barrier after the loads also separates the previous column's LDS reads from this column's writes
+        if constexpr (KIND == PASS_FIRST) {
+#define ZCASE(Z)                                         \
+    case Z:                                              \
+        NP::template load_regs<Z>(a, t, batch, v, tid);  \
+        __syncthreads();                                 \
+        NP::template step0_regs<Z>(a, v, tile, tw, tid); \
+        break;
+            switch (a.zlog) { ZCASE(2) ZCASE(3) ZCASE(4) default: ZCASE(0) }
+#undef ZCASE
+        } else if constexpr (KIND == PASS_MID) {
+            NP::template load_regs<0>(a, t, batch, v, tid);
+            __syncthreads();
+            NP::template step0_regs<0>(a, v, tile, tw, tid);
+        } else {
+            NP::load_rows(a, t, batch, v, tid);
+            if (batch) __syncthreads();
+            NP::rows_to_lds(v, tile, tid);
+            __syncthreads();
+            NP::step0_lds(a, tile, tw, tid);
+        }
+        __syncthreads();
+        if (NP::St::n == 3) {
+            NP::step_mid(a, tile, tw, tid);
+            __syncthreads();
+        }
+        NP::last_step_store_mul(a, t, batch, tile, tw, tid, mw, mq);
+    }
+}
+
 // Measurement aid (smi_ctx_copy_probe): the same tile, the same global loads and the same store
 // addresses as ntt_pass_kernel, no arithmetic and no LDS -- what HBM delivers for this pass's
 // access pattern.  bench.py reports a pass's time against it beside the 8 TB/s peak.
@@ -217,7 +272,10 @@ struct HipLauncher {
         note();
     }
     template <int LR, int LW, int KIND, int CAP> void launch(const PassArgs &a) {
-        ntt_pass_kernel<LR, LW, KIND, CAP><<<dim3(a.n_tiles, a.batch), 1 << (LR + LW - 4), 0, ctx->stream>>>(a);
+        if (ctx->ntt_share_cols && NttPass<LR, LW, KIND, CAP>::share_cols(a))
+            ntt_pass_cols_kernel<LR, LW, KIND, CAP><<<dim3(a.n_tiles, 1), 1 << (LR + LW - 4), 0, ctx->stream>>>(a);
+        else
+            ntt_pass_kernel<LR, LW, KIND, CAP><<<dim3(a.n_tiles, a.batch), 1 << (LR + LW - 4), 0, ctx->stream>>>(a);
     }
     template <int LR, int LW> void launch_probe(int kind, const PassArgs &a) {
         const dim3 grid(a.n_tiles, a.batch);

@@ -477,6 +477,70 @@ template <int LOGR, int LOGW, int KIND, int CAP> struct NttPass {
             }
         }
     }
+
+#ifndef SMI_COLS_MQ   // tuning builds: 0 = keep only the multipliers in registers (16 fewer VGPRs, one multiply more per output)
+#define SMI_COLS_MQ 1
+#endif
+    // ---- all columns of a tile in one workgroup (ntt_pass_kernel's SHARE).  The multipliers of a thread's 16 outputs
+    // -- the inter-pass twiddles of a strided pass, the output scale of a last pass -- depend on the tile and the
+    // thread, not on the column: derived once, in the order last_step_store applies them, with their companions
+    // w * p^-1 so that every application is a three-multiply mont_mul_c.  The products are the canonical residues
+    // last_step_store writes.
+    static SMI_HD bool has_out_mul(const PassArgs &a) { return LAST ? (a.flags & NTT_POST_SCALE) != 0 : !(a.flags & NTT_TW_SKIP); }
+    // The launchers' rule.  Not the first pass: measured on MI355X (gpurun_out/exp_share_cols.log) its 2^14-point
+    // tiles lose more to the registers the multipliers occupy (one workgroup per CU instead of two) or to the
+    // serialised columns than the saved products give back (2^25 x 4: 205-210 us against 197).
+    static SMI_HD bool share_cols(const PassArgs &a) { return !FIRST && a.batch > 1 && has_out_mul(a); }
+    static SMI_HD void out_mul(const PassArgs &a, const TileId &t, uint32_t tid, uint32_t (&mw)[V], uint32_t (&mq)[V]) {
+        enum { NB = (TILE / RL) / NT, KSTEP_LOG = LOGR - SL };
+        const uint32_t w = tid & (W - 1), kb0 = blk_to_k(tid >> LOGW);
+        uint32_t run, step, step_bi = 0;
+        if (!LAST) {
+            const uint32_t b = a.b_off + t.b0 + w, sh = a.T.K - (a.L - a.Sp);
+            run = two_level(a.T.lo, a.T.hi, a.T.h, (b * kb0) << sh, a.F);
+            step = two_level(a.T.lo, a.T.hi, a.T.h, (b << KSTEP_LOG) << sh, a.F);
+            if (NB > 1) step_bi = two_level(a.T.lo, a.T.hi, a.T.h, (b << SL) << sh, a.F);
+        } else {
+            run = two_level(a.S.lo, a.S.hi, a.S.h, (uint32_t)t.out_base + (kb0 << a.Sp) + w, a.F);
+            step = a.post_ratio_m;
+            step_bi = a.post_bi_ratio_m;
+        }
+        const uint32_t sq = step * a.F.pinv, bq = step_bi * a.F.pinv;
+#pragma unroll
+        for (int bi = 0; bi < NB; bi++) {
+            uint32_t cur = run;
+            if (bi + 1 < NB) run = mont_mul_c(run, step_bi, bq, a.F);
+#pragma unroll
+            for (int kk = 0; kk < RL; kk++) {
+                mw[bi * RL + kk] = cur;
+                mq[bi * RL + kk] = SMI_COLS_MQ ? cur * a.F.pinv : 0u;
+                if (kk + 1 < RL) cur = mont_mul_c(cur, step, sq, a.F);
+            }
+        }
+    }
+    static SMI_HD void last_step_store_mul(const PassArgs &a, const TileId &t, uint32_t batch, const uint32_t *tile, const Tw2 *tw,
+                                           uint32_t tid, const uint32_t (&mw)[V], const uint32_t (&mq)[V]) {
+        enum { NB = (TILE / RL) / NT, KSTEP_LOG = LOGR - SL };
+        uint32_t *out = a.out + (uint64_t)batch * a.out_stride + t.out_base;
+        const uint32_t olog = LAST ? a.Sp : a.L - a.Sp - LOGR - a.shard_log;   // log2 of the frequency index's stride in memory
+#pragma unroll
+        for (int bi = 0; bi < NB; bi++) {
+            const uint32_t u = tid + bi * NT;
+            const uint32_t w = u & (W - 1), blk = u >> LOGW;
+            uint32_t x[RL];
+#pragma unroll
+            for (int q = 0; q < RL; q++) x[q] = tile[(blk * RL + q) * WP + w];
+            int m[RL];
+#pragma unroll
+            for (int q = 0; q < RL; q++) m[q] = 2;
+            dft_regs<SL, CAP>(x, m, tw, LOGR - SL, a.F);
+            const uint32_t o0 = (blk_to_k(blk) << olog) + w;
+#pragma unroll
+            for (int kk = 0; kk < RL; kk++)
+                st32(out, o0 + ((uint32_t)kk << (KSTEP_LOG + olog)),
+                     SMI_COLS_MQ ? mont_mul_c(x[brev<SL>(kk)], mw[bi * RL + kk], mq[bi * RL + kk], a.F) : mont_mul(x[brev<SL>(kk)], mw[bi * RL + kk], a.F));
+        }
+    }
 };
 
 // ---- small transforms (n <= 4096): one workgroup per column, radix-4 DIF stages in LDS (a radix-2

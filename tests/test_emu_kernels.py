@@ -247,6 +247,36 @@ def test_emulated_ntt_deferred_first_twiddle(emu, oracle):
         emu.emu_set_defer_tw(0)
 
 
+@pytest.mark.parametrize("L,batch", [(14, 3), (17, 4), (21, 2)])
+def test_emulated_ntt_columns_of_a_tile_in_one_workgroup(emu, oracle, L, batch):
+    """ntt_pass_cols_kernel (csrc/ntt.hip): with more than one column, a middle pass (and a last pass with an
+    output scale) takes every column of its tile in one workgroup and derives the thread's 16 output multipliers
+    once (NttPass::out_mul).  Same results as one workgroup per (tile, column) and as the oracle: forward on a
+    coset, zero-padded (an extension), inverse with its n^-1 / offset^-j output scale."""
+    o = oracle
+    n = 1 << L
+    for p, g in ((P, G), (P2, G2)):
+        w = o.ff_prim_nth_root_g(n, p, g)
+        cols = [o.splitmix64(31 + c, n) % np.uint64(p) for c in range(batch)]
+        cols[-1] = np.full(n, p - 1, dtype=np.uint64)
+        flat = np.concatenate(cols)
+        runs = {}
+        for share in (1, 0):
+            emu.emu_set_share_cols(share)
+            try:
+                runs[share] = (_ntt(emu, p, g, flat, L, n, 0, 3, batch=batch).reshape(batch, n),
+                               _ntt(emu, p, g, flat, L, n // 4, 0, 5, batch=batch, in_stride=n).reshape(batch, n),
+                               _ntt(emu, p, g, flat, L, n, 1, 7, batch=batch).reshape(batch, n))
+            finally:
+                emu.emu_set_share_cols(1)
+        for a, b in zip(runs[1], runs[0]):
+            assert np.array_equal(a, b)
+        for c in range(batch):
+            assert np.array_equal(runs[1][0][c], o.fast_coset_ntt(cols[c], n, w, 3, p))
+            assert np.array_equal(runs[1][1][c], o.fast_coset_ntt(cols[c][:n // 4], n, w, 5, p))
+            assert np.array_equal(runs[1][2][c], o.fast_intt(cols[c], w, 7, p))
+
+
 @pytest.mark.parametrize("geo,lay", [(2, 3), (2, 4), (3, 1), (3, 3), (1, 3), (1, 4)])
 def test_emulated_two_pass_lde_layout_and_tile_geometry_knobs(emu, oracle, geo, lay):
     """the intermediate's block size (lay_kq) and pass B's split of its 16 lines into cosets x adjacent k1
