@@ -245,7 +245,10 @@ def main():
     def twin(k):      # name of the kernel a copy-only twin stands for
         if k.startswith("lde_copy_probe_a"):
             return k.replace("lde_copy_probe_a", "lde_a_kernel")
-        return "lde_b_kernel" if k == "lde_copy_probe_b" else k.replace("ntt_copy_probe", "ntt_pass_kernel")
+        if k == "lde_copy_probe_b":
+            return "lde_b_kernel"
+        cols = k.replace("ntt_copy_probe", "ntt_pass_cols_kernel")   # the pass ran as the column-sharing kernel (csrc/ntt.hip)
+        return cols if cols in kernels else k.replace("ntt_copy_probe", "ntt_pass_kernel")
     probe_ms = {twin(k): v["total_ms"] / v["launches"] for k, v in probes.items()}
     ntt_ms = sum(k["total_ms"] for k in kernels.values()) / prof_steps
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -36,8 +36,9 @@ template <int LOGR, int LOGW, int KIND, int CAP> void emu_pass_cols(const PassAr
     for (uint32_t blk = 0; blk < a.n_tiles; blk++) {
         typename NP::TileId t = NP::tile_id(a, blk);
         for (uint32_t tid = 0; tid < NT; tid++) NP::load_tw(a, tw.data(), tid);
-        for (uint32_t tid = 0; tid < NT; tid++) NP::out_mul(a, t, tid, r16(mw[tid]), r16(mq[tid]));
-        for (uint32_t b = 0; b < a.batch; b++) {
+        for (uint32_t b = 0; b < a.batch; b++) {     // the column groups (grid.y) run the same program one after the other
+            if (b % NP::COLS_PER_WG == 0)            // a new workgroup: its threads derive their multipliers again
+                for (uint32_t tid = 0; tid < NT; tid++) NP::out_mul(a, t, tid, r16(mw[tid]), r16(mq[tid]));
             if (!LAST) {
 #define ZCASE(Z)                                                                                                 \
     case Z:                                                                                                      \
@@ -57,12 +58,14 @@ template <int LOGR, int LOGW, int KIND, int CAP> void emu_pass_cols(const PassAr
     }
 }
 
-bool g_share_cols = true;   // emu_set_share_cols: the launcher's choice (HipLauncher::launch), switchable for the tests
+// emu_set_share_cols: 1 = the launcher's rule (HipLauncher::launch), 0 = never, 2 = whenever the pass has multipliers
+// (the tests' sizes are far below the launch-size threshold of the rule)
+int g_share_cols = 1;
 
 template <int LOGR, int LOGW, int KIND, int CAP> void emu_pass(const PassArgs &a, uint32_t batch) {
     typedef NttPass<LOGR, LOGW, KIND, CAP> NP;
     constexpr bool LAST = KIND == PASS_LAST;
-    if (g_share_cols && NP::share_cols(a)) return emu_pass_cols<LOGR, LOGW, KIND, CAP>(a);
+    if (g_share_cols && NP::share_cols(a, g_share_cols == 2 ? 0u : (uint32_t)NP::COLS_MIN_WGS)) return emu_pass_cols<LOGR, LOGW, KIND, CAP>(a);
     std::vector<uint32_t> tile(NP::R * NP::WP);
     std::vector<Tw2> tw(NP::R);
     for (uint32_t b = 0; b < batch; b++)
@@ -129,7 +132,7 @@ struct EmuLauncher {
 
 static bool g_emu_defer_tw = false;
 extern "C" void emu_set_defer_tw(int on) { g_emu_defer_tw = on != 0; }
-extern "C" void emu_set_share_cols(int on) { g_share_cols = on != 0; }
+extern "C" void emu_set_share_cols(int mode) { g_share_cols = mode; }
 extern "C" int emu_ntt(uint64_t p, uint64_t g, const uint32_t *in, uint32_t *out, uint32_t L, uint32_t n_in,
                        uint32_t batch, uint64_t in_stride, uint64_t out_stride, int inverse, uint64_t offset,
                        uint64_t post_scale) {

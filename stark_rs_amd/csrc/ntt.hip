@@ -51,9 +51,9 @@ __global__ __launch_bounds__(1 << (LOGR + LOGW - 4)) void ntt_pass_kernel(const 
     NP::last_step_store(a, t, batch, tile, tw, tid);
 }
 
-// The same tile program with every column of the tile taken by one workgroup (grid.y = 1): the output multipliers
-// of a thread are derived once and applied to all a.batch columns (NttPass::out_mul).  The launcher picks it when
-// there is more than one column and the pass has output multipliers.
+// The same tile program with up to COLS_PER_WG columns of the tile taken by one workgroup (grid.y = the column groups):
+// the output multipliers of a thread are derived once and applied to all of them (NttPass::out_mul).  The launcher
+// picks it by NttPass::share_cols.
 // Waves per SIMD the register allocation must leave room for, by log2 of the tile (tools/exp_share_cols.sh, 2^25 x 4
 // middle pass): unbounded 81 VGPRs 229 us, 6 waves (73 VGPRs) 222 us, 8 waves (64 VGPRs, 8 spilled) 254 us; one
 // workgroup per (tile, column) 237 us.
@@ -70,7 +70,8 @@ __global__ __launch_bounds__(1 << (LOGR + LOGW - 4), SMI_COLS_WAVES(LOGR + LOGW)
     NP::load_tw(a, tw, tid0);
     uint32_t mw[NP::V], mq[NP::V];
     NP::out_mul(a, t, tid0, mw, mq);
-    for (uint32_t batch = 0; batch < a.batch; batch++) {
+    const uint32_t col0 = blockIdx.y * NP::COLS_PER_WG, col1 = min(a.batch, col0 + (uint32_t)NP::COLS_PER_WG);
+    for (uint32_t batch = col0; batch < col1; batch++) {
         // Opaque per-iteration copy of the thread index: without it every address of the tile program (loop-invariant
         // across the columns) is hoisted and held in registers -- 150 VGPRs, or spills under a bound
         uint32_t tid = tid0;
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(1 << (LOGR + LOGW - 4), SMI_COLS_WAVES(LOGR + LOGW)
             NP::template step0_regs<0>(a, v, tile, tw, tid);
         } else {
             NP::load_rows(a, t, batch, v, tid);
-            if (batch) __syncthreads();
+            if (batch != col0) __syncthreads();
             NP::rows_to_lds(v, tile, tid);
             __syncthreads();
             NP::step0_lds(a, tile, tw, tid);
@@ -273,7 +274,7 @@ struct HipLauncher {
     }
     template <int LR, int LW, int KIND, int CAP> void launch(const PassArgs &a) {
         if (ctx->ntt_share_cols && NttPass<LR, LW, KIND, CAP>::share_cols(a))
-            ntt_pass_cols_kernel<LR, LW, KIND, CAP><<<dim3(a.n_tiles, 1), 1 << (LR + LW - 4), 0, ctx->stream>>>(a);
+            ntt_pass_cols_kernel<LR, LW, KIND, CAP><<<dim3(a.n_tiles, NttPass<LR, LW, KIND, CAP>::col_groups(a)), 1 << (LR + LW - 4), 0, ctx->stream>>>(a);
         else
             ntt_pass_kernel<LR, LW, KIND, CAP><<<dim3(a.n_tiles, a.batch), 1 << (LR + LW - 4), 0, ctx->stream>>>(a);
     }
@@ -303,7 +304,10 @@ struct HipLauncher {
             note();                                                                                            \
             return;                                                                                            \
         }                                                                                                      \
-        ProfScope ps(ctx, kind == PASS_LAST ? "ntt_pass_kernel<" #LR "," #LW ",last>" : kind == PASS_MID ? "ntt_pass_kernel<" #LR "," #LW ",mid>" : "ntt_pass_kernel<" #LR "," #LW ",first>", bytes); \
+        const bool cols = ctx->ntt_share_cols && (kind == PASS_LAST ? NttPass<LR, LW, PASS_LAST, 4>::share_cols(a)                     \
+                                                  : kind == PASS_MID ? NttPass<LR, LW, PASS_MID, 4>::share_cols(a) : false);            \
+        ProfScope ps(ctx, cols ? (kind == PASS_LAST ? "ntt_pass_cols_kernel<" #LR "," #LW ",last>" : "ntt_pass_cols_kernel<" #LR "," #LW ",mid>") \
+                          : kind == PASS_LAST ? "ntt_pass_kernel<" #LR "," #LW ",last>" : kind == PASS_MID ? "ntt_pass_kernel<" #LR "," #LW ",mid>" : "ntt_pass_kernel<" #LR "," #LW ",first>", bytes); \
         if (wide) launch_kind<LR, LW, 8>(kind, a);                                                             \
         else launch_kind<LR, LW, 4>(kind, a);                                                                  \
         note();                                                                                                \

@@ -490,7 +490,13 @@ template <int LOGR, int LOGW, int KIND, int CAP> struct NttPass {
     // The launchers' rule.  Not the first pass: measured on MI355X (gpurun_out/exp_share_cols.log) its 2^14-point
     // tiles lose more to the registers the multipliers occupy (one workgroup per CU instead of two) or to the
     // serialised columns than the saved products give back (2^25 x 4: 205-210 us against 197).
-    static SMI_HD bool share_cols(const PassArgs &a) { return !FIRST && a.batch > 1 && has_out_mul(a); }
+    // At most COLS_PER_WG columns per workgroup (grid.y = the column groups), and only while the launch still has
+    // enough workgroups to fill the chip -- many short columns keep one workgroup per (tile, column).
+    enum { COLS_PER_WG = 4, COLS_MIN_WGS = 1024 };
+    static SMI_HD uint32_t col_groups(const PassArgs &a) { return (a.batch + COLS_PER_WG - 1) / COLS_PER_WG; }
+    static SMI_HD bool share_cols(const PassArgs &a, uint32_t min_wgs = COLS_MIN_WGS) {
+        return !FIRST && a.batch > 1 && has_out_mul(a) && (uint64_t)a.n_tiles * col_groups(a) >= min_wgs;
+    }
     static SMI_HD void out_mul(const PassArgs &a, const TileId &t, uint32_t tid, uint32_t (&mw)[V], uint32_t (&mq)[V]) {
         enum { NB = (TILE / RL) / NT, KSTEP_LOG = LOGR - SL };
         const uint32_t w = tid & (W - 1), kb0 = blk_to_k(tid >> LOGW);

@@ -247,11 +247,11 @@ def test_emulated_ntt_deferred_first_twiddle(emu, oracle):
         emu.emu_set_defer_tw(0)
 
 
-@pytest.mark.parametrize("L,batch", [(14, 3), (17, 4), (21, 2)])
+@pytest.mark.parametrize("L,batch", [(14, 3), (17, 6), (21, 2)])
 def test_emulated_ntt_columns_of_a_tile_in_one_workgroup(emu, oracle, L, batch):
     """ntt_pass_cols_kernel (csrc/ntt.hip): with more than one column, a middle pass (and a last pass with an
     output scale) takes every column of its tile in one workgroup and derives the thread's 16 output multipliers
-    once (NttPass::out_mul).  Same results as one workgroup per (tile, column) and as the oracle: forward on a
+    once (NttPass::out_mul), four columns per workgroup.  Same results as one workgroup per (tile, column) and as the oracle: forward on a
     coset, zero-padded (an extension), inverse with its n^-1 / offset^-j output scale."""
     o = oracle
     n = 1 << L
@@ -261,7 +261,7 @@ def test_emulated_ntt_columns_of_a_tile_in_one_workgroup(emu, oracle, L, batch):
         cols[-1] = np.full(n, p - 1, dtype=np.uint64)
         flat = np.concatenate(cols)
         runs = {}
-        for share in (1, 0):
+        for share in (2, 0):          # 2: whenever the pass has multipliers (the launch-size threshold of the rule aside)
             emu.emu_set_share_cols(share)
             try:
                 runs[share] = (_ntt(emu, p, g, flat, L, n, 0, 3, batch=batch).reshape(batch, n),
@@ -269,12 +269,12 @@ def test_emulated_ntt_columns_of_a_tile_in_one_workgroup(emu, oracle, L, batch):
                                _ntt(emu, p, g, flat, L, n, 1, 7, batch=batch).reshape(batch, n))
             finally:
                 emu.emu_set_share_cols(1)
-        for a, b in zip(runs[1], runs[0]):
+        for a, b in zip(runs[2], runs[0]):
             assert np.array_equal(a, b)
         for c in range(batch):
-            assert np.array_equal(runs[1][0][c], o.fast_coset_ntt(cols[c], n, w, 3, p))
-            assert np.array_equal(runs[1][1][c], o.fast_coset_ntt(cols[c][:n // 4], n, w, 5, p))
-            assert np.array_equal(runs[1][2][c], o.fast_intt(cols[c], w, 7, p))
+            assert np.array_equal(runs[2][0][c], o.fast_coset_ntt(cols[c], n, w, 3, p))
+            assert np.array_equal(runs[2][1][c], o.fast_coset_ntt(cols[c][:n // 4], n, w, 5, p))
+            assert np.array_equal(runs[2][2][c], o.fast_intt(cols[c], w, 7, p))
 
 
 @pytest.mark.parametrize("geo,lay", [(2, 3), (2, 4), (3, 1), (3, 3), (1, 3), (1, 4)])

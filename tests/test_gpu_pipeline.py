@@ -328,6 +328,34 @@ def test_two_pass_lde_equals_oracle(eng, eng2, oracle, which, logn, lb, W):
     e.dev_free(d_out)
 
 
+@pytest.mark.parametrize("which,logn,lb,W", [("ref", 19, 3, 6), ("second", 20, 3, 2), ("second", 22, 1, 5)])
+def test_lde_with_the_columns_of_a_tile_in_one_workgroup(eng, eng2, oracle, which, logn, lb, W):
+    """ntt_pass_cols_kernel (csrc/ntt.hip): middle passes and the inverse transforms' scaled last passes take up to
+    four columns of a tile per workgroup and derive each thread's 16 output multipliers once.  Whole columns
+    against the oracle (interpolate_domain + eval_domain restated, src/univariate/interpolate.rs:6-44,
+    eval.rs:16-21), with one and with two column groups, and the launch seen in the profile."""
+    o = oracle
+    e, p, g = (eng, P, G) if which == "ref" else (eng2, P2, G2)
+    n, N = 1 << logn, 1 << (logn + lb)
+    w, Wn = o.ff_prim_nth_root_g(n, p, g), o.ff_prim_nth_root_g(N, p, g)
+    cols = np.stack([_vals(o, 1300 + 5 * logn + c, n, p) for c in range(W)])
+    cols[W - 1, :] = p - 1                       # lazy sums at their bounds
+    d_in = _upload(e, cols)
+    d_out = e.dev_alloc(W * N * 4)
+    e.profile(True)
+    e.dev_lde(d_in, W, logn, lb, d_out, 1, g)
+    names = e.profile_read()
+    e.profile(False)
+    assert any(k.startswith("ntt_pass_cols_kernel") and k.endswith("mid>") for k in names), names
+    if logn >= 22:   # enough tiles for the inverse transforms' scaled last pass to share as well (NttPass::share_cols)
+        assert any(k.startswith("ntt_pass_cols_kernel") and k.endswith("last>") for k in names), names
+    got = e.dev_download(d_out, W * N).reshape(W, N)
+    for c in range(W):
+        assert np.array_equal(got[c], o.fast_coset_ntt(o.fast_intt(cols[c], w, 1, p), N, Wn, g, p)), c
+    e.dev_free(d_in)
+    e.dev_free(d_out)
+
+
 @pytest.mark.parametrize("which", ["ref_prime", "second_prime"])
 def test_stark_prove_column_openings(eng, eng2, oracle, which):
     """smi_stark_cfg.open_columns: the FRI proof bytes are unchanged, the appended openings are byte for byte

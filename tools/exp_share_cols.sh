@@ -7,7 +7,7 @@ B="python3 bench.py --no-extras --steps 20 --warmup 3"
 show() { python3 -c "
 import json,sys
 r=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); k=r['roofline']['kernels']
-print(sys.argv[2], 'ms_per_step %.4f'%r['ms_per_step'], ' '.join('%s %.0f'%(n.replace('ntt_pass_kernel',''),v['avg_ms']*1e3) for n,v in k.items() if 'pass' in n))
+print(sys.argv[2], 'ms_per_step %.4f'%r['ms_per_step'], ' '.join('%s %.0f'%(n.replace('ntt_pass_kernel','').replace('ntt_pass_cols_kernel','cols'),v['avg_ms']*1e3) for n,v in k.items() if 'pass' in n))
 " $1 $2; }
 for i in 1 2 3; do
 $B > gpurun_out/sc_on.json;  show gpurun_out/sc_on.json default

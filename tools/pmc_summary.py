@@ -18,9 +18,9 @@ KIND = {"0": "first", "1": "mid", "2": "last"}
 
 def bench_name(sym):
     """rocprofv3 kernel symbol -> the name bench.py / smi_ctx_profile use."""
-    m = re.search(r"ntt_pass(?:_cols)?_kernel<(\d+), (\d+), (\d+), \d+>", sym)   # _cols: all columns of a tile per workgroup
+    m = re.search(r"ntt_pass(_cols)?_kernel<(\d+), (\d+), (\d+), \d+>", sym)   # _cols: the columns of a tile per workgroup
     if m:
-        return f"ntt_pass_kernel<{m.group(1)},{m.group(2)},{KIND[m.group(3)]}>"
+        return f"ntt_pass{m.group(1) or ''}_kernel<{m.group(2)},{m.group(3)},{KIND[m.group(4)]}>"
     m = re.search(r"lde_a_kernel<(\d+), \d+>", sym)
     if m:
         return f"lde_a_kernel<{m.group(1)}>"
@@ -50,7 +50,7 @@ def summarise(src, suffix=""):
     fetch, write, valu = (counters(os.path.join(src, d + suffix)) for d in ("fetch", "write", "valu"))
     summary = {}
     for k in sorted(set(fetch) | set(write)):
-        if not (k.startswith("ntt_pass_kernel") or k.startswith("lde_")):
+        if not (k.startswith("ntt_pass_") or k.startswith("lde_")):
             continue
         f = fetch.get(k, {}).get("FETCH_SIZE", [])
         w = write.get(k, {}).get("WRITE_SIZE", [])
