@@ -31,15 +31,25 @@ template <int LOGR, int LOGW, int KIND, int CAP> void emu_pass_cols(const PassAr
     const uint32_t NT = NP::NT;
     std::vector<uint32_t> tile(NP::R * NP::WP);
     std::vector<Tw2> tw(NP::R);
-    std::vector<std::array<uint32_t, 16>> mw(NT), mq(NT), regs(NT);
+    std::vector<std::array<uint32_t, 16>> mw(NT), mq(NT), iw(NT), regs(NT);
+    const bool twin = KIND == PASS_MID && (a.flags & NTT_TW_IN);   // ntt_pass_cols_kernel<..., TWIN>
     auto r16 = [](std::array<uint32_t, 16> &x) -> uint32_t(&)[16] { return reinterpret_cast<uint32_t(&)[16]>(x); };
     for (uint32_t blk = 0; blk < a.n_tiles; blk++) {
         typename NP::TileId t = NP::tile_id(a, blk);
         for (uint32_t tid = 0; tid < NT; tid++) NP::load_tw(a, tw.data(), tid);
         for (uint32_t b = 0; b < a.batch; b++) {     // the column groups (grid.y) run the same program one after the other
             if (b % NP::COLS_PER_WG == 0)            // a new workgroup: its threads derive their multipliers again
-                for (uint32_t tid = 0; tid < NT; tid++) NP::out_mul(a, t, tid, r16(mw[tid]), r16(mq[tid]));
-            if (!LAST) {
+                for (uint32_t tid = 0; tid < NT; tid++) {
+                    NP::out_mul(a, t, tid, r16(mw[tid]), r16(mq[tid]));
+                    if (twin) NP::in_mul(a, t, tid, r16(iw[tid]));
+                }
+            if (twin) {
+                for (uint32_t tid = 0; tid < NT; tid++) {
+                    NP::template load_regs<0, false>(a, t, b, r16(regs[tid]), tid);
+                    for (int i = 0; i < 16; i++) regs[tid][i] = mont_mul(regs[tid][i], iw[tid][i], a.F);
+                }
+                for (uint32_t tid = 0; tid < NT; tid++) NP::template step0_regs<0>(a, r16(regs[tid]), tile.data(), tw.data(), tid);
+            } else if (!LAST) {
 #define ZCASE(Z)                                                                                                 \
     case Z:                                                                                                      \
         for (uint32_t tid = 0; tid < NT; tid++) NP::template load_regs<Z>(a, t, b, r16(regs[tid]), tid);         \
@@ -130,8 +140,8 @@ struct EmuLauncher {
 
 }  // namespace
 
-static bool g_emu_defer_tw = false;
-extern "C" void emu_set_defer_tw(int on) { g_emu_defer_tw = on != 0; }
+static int g_emu_defer_tw = 2;   // NttRequest::defer_tw: 0 never, 1 always, 2 the driver's rule
+extern "C" void emu_set_defer_tw(int mode) { g_emu_defer_tw = mode; }
 extern "C" void emu_set_share_cols(int mode) { g_share_cols = mode; }
 extern "C" int emu_ntt(uint64_t p, uint64_t g, const uint32_t *in, uint32_t *out, uint32_t L, uint32_t n_in,
                        uint32_t batch, uint64_t in_stride, uint64_t out_stride, int inverse, uint64_t offset,

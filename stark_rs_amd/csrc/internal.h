@@ -42,7 +42,8 @@ struct smi_ctx {
     bool copy_probe = false;       // smi_ctx_copy_probe: NTT passes launch their copy-only twins
     // three-pass transforms: the second pass applies the first pass's inter-pass twiddle as it loads (ntt_core.h)
     bool ntt_share_cols = !(getenv("SMI_NTT_SHARE_COLS") && atoi(getenv("SMI_NTT_SHARE_COLS")) == 0);   // tuning knob, default on
-    bool ntt_defer_tw = !(getenv("SMI_NTT_DEFER_TW") && atoi(getenv("SMI_NTT_DEFER_TW")) == 0) && getenv("SMI_NTT_DEFER_TW") != nullptr;
+    bool ntt_twin_regs = !(getenv("SMI_NTT_TWIN_REGS") && atoi(getenv("SMI_NTT_TWIN_REGS")) == 0);   // tuning knob, default on: deferred twiddles held as per-thread input multipliers
+    int ntt_defer_tw = getenv("SMI_NTT_DEFER_TW") ? (atoi(getenv("SMI_NTT_DEFER_TW")) != 0) : 2;   // NttRequest::defer_tw; tuning knob, default 2 (auto)
     bool lde_two_pass = getenv("SMI_LDE_TWO_PASS") && atoi(getenv("SMI_LDE_TWO_PASS"));   // smi_ctx_lde_two_pass
     std::vector<ProfRec> prof;
     // bump arena for the per-prove device buffers (trees, folded codewords, proof bytes):

@@ -60,16 +60,25 @@ __global__ __launch_bounds__(1 << (LOGR + LOGW - 4)) void ntt_pass_kernel(const 
 #ifndef SMI_COLS_WAVES
 #define SMI_COLS_WAVES(TILE_LOG) ((TILE_LOG) >= 14 ? 4 : 6)
 #endif
-template <int LOGR, int LOGW, int KIND, int CAP>
-__global__ __launch_bounds__(1 << (LOGR + LOGW - 4), SMI_COLS_WAVES(LOGR + LOGW)) void ntt_pass_cols_kernel(const PassArgs a) {
+#ifndef SMI_COLS_TWIN_WAVES   // tuning builds: the bound and the companions of the variant that also holds input multipliers
+#define SMI_COLS_TWIN_WAVES 4
+#endif
+#ifndef SMI_COLS_TWIN_MQ
+#define SMI_COLS_TWIN_MQ 1
+#endif
+template <int LOGR, int LOGW, int KIND, int CAP, bool TWIN = false>   // TWIN: the previous pass left its twiddles to this one (NTT_TW_IN)
+__global__ __launch_bounds__(1 << (LOGR + LOGW - 4), TWIN ? SMI_COLS_TWIN_WAVES : SMI_COLS_WAVES(LOGR + LOGW)) void ntt_pass_cols_kernel(const PassArgs a) {
     typedef NttPass<LOGR, LOGW, KIND, CAP> NP;
     __shared__ uint32_t tile[NP::R * NP::WP];
     __shared__ Tw2 tw[NP::R];
     const uint32_t tid0 = threadIdx.x;
     const typename NP::TileId t = NP::tile_id(a, blockIdx.x);
     NP::load_tw(a, tw, tid0);
-    uint32_t mw[NP::V], mq[NP::V];
-    NP::out_mul(a, t, tid0, mw, mq);
+    constexpr bool MQ = !TWIN || SMI_COLS_TWIN_MQ;
+    uint32_t mw[NP::V], mq[MQ ? NP::V : 1];
+    NP::template out_mul<MQ>(a, t, tid0, mw, mq);
+    uint32_t iw[TWIN ? NP::V : 1];
+    if constexpr (TWIN) NP::in_mul(a, t, tid0, iw);
     const uint32_t col0 = blockIdx.y * NP::COLS_PER_WG, col1 = min(a.batch, col0 + (uint32_t)NP::COLS_PER_WG);
     for (uint32_t batch = col0; batch < col1; batch++) {
         // Opaque per-iteration copy of the thread index: without it every address of the tile program (loop-invariant
@@ -88,7 +97,11 @@ __global__ __launch_bounds__(1 << (LOGR + LOGW - 4), SMI_COLS_WAVES(LOGR + LOGW)
             switch (a.zlog) { ZCASE(2) ZCASE(3) ZCASE(4) default: ZCASE(0) }
 #undef ZCASE
         } else if constexpr (KIND == PASS_MID) {
-            NP::template load_regs<0>(a, t, batch, v, tid);
+            NP::template load_regs<0, !TWIN>(a, t, batch, v, tid);
+            if constexpr (TWIN) {
+#pragma unroll
+                for (int i = 0; i < NP::V; i++) v[i] = mont_mul(v[i], iw[i], a.F);
+            }
             __syncthreads();
             NP::template step0_regs<0>(a, v, tile, tw, tid);
         } else {
@@ -103,7 +116,7 @@ __global__ __launch_bounds__(1 << (LOGR + LOGW - 4), SMI_COLS_WAVES(LOGR + LOGW)
             NP::step_mid(a, tile, tw, tid);
             __syncthreads();
         }
-        NP::last_step_store_mul(a, t, batch, tile, tw, tid, mw, mq);
+        NP::template last_step_store_mul<MQ>(a, t, batch, tile, tw, tid, mw, mq);
     }
 }
 
@@ -273,8 +286,13 @@ struct HipLauncher {
         note();
     }
     template <int LR, int LW, int KIND, int CAP> void launch(const PassArgs &a) {
-        if (ctx->ntt_share_cols && NttPass<LR, LW, KIND, CAP>::share_cols(a))
-            ntt_pass_cols_kernel<LR, LW, KIND, CAP><<<dim3(a.n_tiles, NttPass<LR, LW, KIND, CAP>::col_groups(a)), 1 << (LR + LW - 4), 0, ctx->stream>>>(a);
+        if (ctx->ntt_share_cols && NttPass<LR, LW, KIND, CAP>::share_cols(a)) {
+            const dim3 grid(a.n_tiles, NttPass<LR, LW, KIND, CAP>::col_groups(a));
+            if (KIND == PASS_MID && (a.flags & NTT_TW_IN) && ctx->ntt_twin_regs)
+                ntt_pass_cols_kernel<LR, LW, KIND, CAP, KIND == PASS_MID><<<grid, 1 << (LR + LW - 4), 0, ctx->stream>>>(a);
+            else
+                ntt_pass_cols_kernel<LR, LW, KIND, CAP><<<grid, 1 << (LR + LW - 4), 0, ctx->stream>>>(a);
+        }
         else
             ntt_pass_kernel<LR, LW, KIND, CAP><<<dim3(a.n_tiles, a.batch), 1 << (LR + LW - 4), 0, ctx->stream>>>(a);
     }

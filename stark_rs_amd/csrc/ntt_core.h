@@ -95,6 +95,10 @@ struct PassArgs {
 
 // digit structure of the in-tile transform; s0 = 4 everywhere, so the 16 values a thread loads in
 // a strided pass (rows j0 + i*R/16) are exactly the inputs of its one radix-16 butterfly.
+// ntt_pass_cols_kernel (NttPass::share_cols): columns of a tile per workgroup, and the fewest workgroups a launch may
+// have for it; the driver's choice to defer the first pass's twiddles (ntt_driver.h) uses the same numbers
+enum { SMI_COLS_PER_WG = 4, SMI_COLS_MIN_WGS = 1024 };
+
 template <int LOGR> struct Steps;
 template <> struct Steps<6>  { enum { n = 2, s0 = 4, s1 = 2, s2 = 0 }; };
 template <> struct Steps<7>  { enum { n = 2, s0 = 4, s1 = 3, s2 = 0 }; };
@@ -272,7 +276,8 @@ template <int LOGR, int LOGW, int KIND, int CAP> struct NttPass {
     // ---- strided passes: the 16 global loads of a thread are rows j0 + i*(R/16) of column w --
     // exactly the inputs of its radix-16 butterfly (pos = j0), so step 0 runs on them directly.
     // Z: rows i >= 16 >> Z are zero padding and are neither loaded nor scaled.
-    template <int Z> static SMI_HD void load_regs(const PassArgs &a, const TileId &t, uint32_t batch, uint32_t (&v)[V], uint32_t tid) {
+    // TWIN = false: a caller that holds the deferred twiddles itself (in_mul) applies them after the loads.
+    template <int Z, bool TWIN = true> static SMI_HD void load_regs(const PassArgs &a, const TileId &t, uint32_t batch, uint32_t (&v)[V], uint32_t tid) {
         const uint32_t blog = a.L - a.Sp - LOGR, ablog = blog - a.shard_log;
         const uint32_t w = tid & (W - 1), j0 = tid >> LOGW;
         const uint32_t o0 = (j0 << ablog) + w;              // address within the tile's rows
@@ -303,7 +308,7 @@ template <int LOGR, int LOGW, int KIND, int CAP> struct NttPass {
             const uint32_t *in = a.in + (uint64_t)batch * a.in_stride + t.in_base;
 #pragma unroll
             for (int i = 0; i < V; i++) v[i] = ld32(in, o0 + ((uint32_t)(i * (NT >> LOGW)) << ablog));
-            if (a.flags & NTT_TW_IN) {
+            if (TWIN && (a.flags & NTT_TW_IN)) {
                 // the previous pass's w_m'^(k b'), m' = 2^(L - Sp + prev_logr): k = its output digit = the low
                 // prev_logr bits of this tile's sub-problem index, b' = (row << blog) + column; along a
                 // thread's rows a geometric sequence whose ratio is the same for the whole tile
@@ -478,9 +483,6 @@ template <int LOGR, int LOGW, int KIND, int CAP> struct NttPass {
         }
     }
 
-#ifndef SMI_COLS_MQ   // tuning builds: 0 = keep only the multipliers in registers (16 fewer VGPRs, one multiply more per output)
-#define SMI_COLS_MQ 1
-#endif
     // ---- all columns of a tile in one workgroup (ntt_pass_kernel's SHARE).  The multipliers of a thread's 16 outputs
     // -- the inter-pass twiddles of a strided pass, the output scale of a last pass -- depend on the tile and the
     // thread, not on the column: derived once, in the order last_step_store applies them, with their companions
@@ -492,12 +494,14 @@ template <int LOGR, int LOGW, int KIND, int CAP> struct NttPass {
     // serialised columns than the saved products give back (2^25 x 4: 205-210 us against 197).
     // At most COLS_PER_WG columns per workgroup (grid.y = the column groups), and only while the launch still has
     // enough workgroups to fill the chip -- many short columns keep one workgroup per (tile, column).
-    enum { COLS_PER_WG = 4, COLS_MIN_WGS = 1024 };
+    enum { COLS_PER_WG = SMI_COLS_PER_WG, COLS_MIN_WGS = SMI_COLS_MIN_WGS };
     static SMI_HD uint32_t col_groups(const PassArgs &a) { return (a.batch + COLS_PER_WG - 1) / COLS_PER_WG; }
     static SMI_HD bool share_cols(const PassArgs &a, uint32_t min_wgs = COLS_MIN_WGS) {
         return !FIRST && a.batch > 1 && has_out_mul(a) && (uint64_t)a.n_tiles * col_groups(a) >= min_wgs;
     }
-    static SMI_HD void out_mul(const PassArgs &a, const TileId &t, uint32_t tid, uint32_t (&mw)[V], uint32_t (&mq)[V]) {
+    // MQ = false: only the multipliers are kept (16 fewer VGPRs, one multiply more per output).
+    template <bool MQ = true>
+    static SMI_HD void out_mul(const PassArgs &a, const TileId &t, uint32_t tid, uint32_t (&mw)[V], uint32_t (&mq)[MQ ? V : 1]) {
         enum { NB = (TILE / RL) / NT, KSTEP_LOG = LOGR - SL };
         const uint32_t w = tid & (W - 1), kb0 = blk_to_k(tid >> LOGW);
         uint32_t run, step, step_bi = 0;
@@ -519,13 +523,30 @@ template <int LOGR, int LOGW, int KIND, int CAP> struct NttPass {
 #pragma unroll
             for (int kk = 0; kk < RL; kk++) {
                 mw[bi * RL + kk] = cur;
-                mq[bi * RL + kk] = SMI_COLS_MQ ? cur * a.F.pinv : 0u;
+                if constexpr (MQ) mq[bi * RL + kk] = cur * a.F.pinv;
                 if (kk + 1 < RL) cur = mont_mul_c(cur, step, sq, a.F);
             }
         }
     }
+    // The deferred twiddles of load_regs (NTT_TW_IN) as the thread's 16 input multipliers: like the output multipliers
+    // they depend on the tile and the thread only.  Same sequence as load_regs derives on the fly.
+    static SMI_HD void in_mul(const PassArgs &a, const TileId &t, uint32_t tid, uint32_t (&iw)[V]) {
+        const uint32_t blog = a.L - a.Sp - LOGR;
+        const uint32_t w = tid & (W - 1), j0 = tid >> LOGW;
+        const uint32_t sub = (uint32_t)(t.in_base >> (a.L - a.Sp)), k = sub & ((1u << a.prev_logr) - 1u);
+        const uint32_t sh = a.T.K - (a.L - a.Sp + a.prev_logr);
+        uint32_t cur = two_level(a.T.lo, a.T.hi, a.T.h, (k * ((j0 << blog) + t.b0 + w)) << sh, a.F);
+        const uint32_t ratio = two_level(a.T.lo, a.T.hi, a.T.h, (k * ((uint32_t)(NT >> LOGW) << blog)) << sh, a.F);
+        const uint32_t rq = ratio * a.F.pinv;
+#pragma unroll
+        for (int i = 0; i < V; i++) {
+            iw[i] = cur;
+            if (i + 1 < V) cur = mont_mul_c(cur, ratio, rq, a.F);
+        }
+    }
+    template <bool MQ = true>
     static SMI_HD void last_step_store_mul(const PassArgs &a, const TileId &t, uint32_t batch, const uint32_t *tile, const Tw2 *tw,
-                                           uint32_t tid, const uint32_t (&mw)[V], const uint32_t (&mq)[V]) {
+                                           uint32_t tid, const uint32_t (&mw)[V], const uint32_t (&mq)[MQ ? V : 1]) {
         enum { NB = (TILE / RL) / NT, KSTEP_LOG = LOGR - SL };
         uint32_t *out = a.out + (uint64_t)batch * a.out_stride + t.out_base;
         const uint32_t olog = LAST ? a.Sp : a.L - a.Sp - LOGR - a.shard_log;   // log2 of the frequency index's stride in memory
@@ -543,8 +564,8 @@ template <int LOGR, int LOGW, int KIND, int CAP> struct NttPass {
             const uint32_t o0 = (blk_to_k(blk) << olog) + w;
 #pragma unroll
             for (int kk = 0; kk < RL; kk++)
-                st32(out, o0 + ((uint32_t)kk << (KSTEP_LOG + olog)),
-                     SMI_COLS_MQ ? mont_mul_c(x[brev<SL>(kk)], mw[bi * RL + kk], mq[bi * RL + kk], a.F) : mont_mul(x[brev<SL>(kk)], mw[bi * RL + kk], a.F));
+                if constexpr (MQ) st32(out, o0 + ((uint32_t)kk << (KSTEP_LOG + olog)), mont_mul_c(x[brev<SL>(kk)], mw[bi * RL + kk], mq[bi * RL + kk], a.F));
+                else st32(out, o0 + ((uint32_t)kk << (KSTEP_LOG + olog)), mont_mul(x[brev<SL>(kk)], mw[bi * RL + kk], a.F));
         }
     }
 };

@@ -18,7 +18,10 @@ struct NttRequest {
     bool pre_scale;      // multiply input i by S(i)   (coset shift of a forward transform)
     bool post_scale;     // multiply output k by S(k)  (n^-1 * offset^-k of an inverse transform)
     uint32_t q_plain;    // ratio of the scale sequence S(i) = c * q^i (plain form)
-    bool defer_tw;       // three or more passes: the first pass's inter-pass twiddle is applied by the second as it loads
+    int defer_tw;        // three or more passes: the first pass's inter-pass twiddle is applied by the second as it loads --
+                         // 0 never, 1 always, 2 when the second pass takes the columns of a tile per workgroup (it then
+                         // derives them once per thread for all of them, NttPass::in_mul: 2^25 x 4 first pass 199 -> 148 us,
+                         // second 223 -> 250 us, gpurun_out/exp_defer_cols3.log; with one column per workgroup a wash)
 };
 
 // Launcher concept:
@@ -38,6 +41,8 @@ template <class Launcher> inline bool ntt_run(Launcher &ln, const NttRequest &rq
     if (!rq.scratch) return false;
     const uint64_t n = 1ull << rq.L;
     uint32_t consumed = 0;
+    const uint64_t wgs1 = pl.np >= 3 ? (n >> (pl.logr[1] + pl.logw[1])) * ((rq.batch + SMI_COLS_PER_WG - 1) / SMI_COLS_PER_WG) : 0;
+    const bool defer = pl.np >= 3 && (rq.defer_tw == 1 || (rq.defer_tw == 2 && rq.batch > 1 && wgs1 >= SMI_COLS_MIN_WGS));
     for (int p = 0; p < pl.np; p++) {
         const bool first = p == 0, last = p == pl.np - 1;
         PassArgs a;
@@ -50,8 +55,8 @@ template <class Launcher> inline bool ntt_run(Launcher &ln, const NttRequest &rq
         a.L = rq.L; a.Sp = consumed; a.n_in = rq.n_in;
         a.flags = (first ? NTT_FIRST : 0) | (first && rq.pre_scale ? NTT_PRE_SCALE : 0) |
                   (last && rq.post_scale ? NTT_POST_SCALE : 0);
-        if (rq.defer_tw && pl.np >= 3 && p == 0) a.flags |= NTT_TW_SKIP;
-        if (rq.defer_tw && pl.np >= 3 && p == 1) {
+        if (defer && p == 0) a.flags |= NTT_TW_SKIP;
+        if (defer && p == 1) {
             a.flags |= NTT_TW_IN;
             a.prev_logr = (uint32_t)pl.logr[0];
         }

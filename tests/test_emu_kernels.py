@@ -232,7 +232,10 @@ def test_emulated_ntt_deferred_first_twiddle(emu, oracle):
     n = 1 << L
     emu.emu_set_defer_tw(1)
     try:
-        for p, g in ((P, G), (P2, G2)):
+        # second prime again with the columns of a tile in one workgroup: the deferred twiddles become 16 per-thread
+        # input multipliers derived once (NttPass::in_mul, ntt_pass_cols_kernel<..., TWIN>)
+        for p, g, share in ((P, G, 1), (P2, G2, 1), (P2, G2, 2)):
+            emu.emu_set_share_cols(share)
             w = o.ff_prim_nth_root_g(n, p, g)
             a, b = o.splitmix64(7, n) % np.uint64(p), np.full(n, p - 1, dtype=np.uint64)
             both = np.concatenate([a, b])
@@ -244,7 +247,8 @@ def test_emulated_ntt_deferred_first_twiddle(emu, oracle):
             got = _ntt(emu, p, g, both, L, n, 1, 1, batch=2).reshape(2, n)
             assert np.array_equal(got[0], o.fast_intt(a, w, 1, p)) and np.array_equal(got[1], o.fast_intt(b, w, 1, p))
     finally:
-        emu.emu_set_defer_tw(0)
+        emu.emu_set_defer_tw(2)
+        emu.emu_set_share_cols(1)
 
 
 @pytest.mark.parametrize("L,batch", [(14, 3), (17, 6), (21, 2)])
