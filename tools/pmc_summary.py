@@ -18,7 +18,7 @@ KIND = {"0": "first", "1": "mid", "2": "last"}
 
 def bench_name(sym):
     """rocprofv3 kernel symbol -> the name bench.py / smi_ctx_profile use."""
-    m = re.search(r"ntt_pass(_cols)?_kernel<(\d+), (\d+), (\d+), \d+>", sym)   # _cols: the columns of a tile per workgroup
+    m = re.search(r"ntt_pass(_cols)?_kernel<(\d+), (\d+), (\d+), \d+(?:, \w+)?>", sym)   # _cols: the columns of a tile per workgroup
     if m:
         return f"ntt_pass{m.group(1) or ''}_kernel<{m.group(2)},{m.group(3)},{KIND[m.group(4)]}>"
     m = re.search(r"lde_a_kernel<(\d+), \d+>", sym)
