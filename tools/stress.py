@@ -5,7 +5,7 @@ NTT / iNTT at random sizes, offsets and paddings on both primes, Merkle trees (e
 leaves), folds, FRI proofs (byte-identical to the oracle's), polynomial products and divisions,
 smi_fri_verify against the oracle's verdict on tampered proofs, the whole prove with column openings
 (single-GPU and through the multi-GPU entry points at world size 1) + smi_stark_verify, and the
-two-pass extension."""
+two-pass extension, many-column extensions (the column-sharing pass kernels)."""
 import os
 import sys
 import time
@@ -30,7 +30,7 @@ def main():
     while time.time() - t0 < budget:
         p = int(rng.choice([s.P_REF, s.P2]))
         e, g = engs[p], gens[p]
-        kind = rng.integers(0, 10)
+        kind = rng.integers(0, 11)
         if kind == 0:      # inverse transform
             L = int(rng.integers(0, 22))
             n = 1 << L
@@ -165,6 +165,23 @@ def main():
             assert np.array_equal(e.dev_download(d_a, W * N), e.dev_download(d_b, W * N)), ("two-pass lde", logn, lb, W)
             for d in (d_cols, d_a, d_b):
                 e.dev_free(d)
+        elif kind == 10:                   # many-column extension: the column-sharing pass kernels (one or more column groups,
+            # deferred first-pass twiddles) at launch sizes that select them; two random columns against the oracle
+            logn, lb, W = int(rng.integers(18, 22)), int(rng.integers(1, 4)), int(rng.integers(2, 10))
+            if logn + lb > (23 if p == s.P_REF else 24):
+                continue
+            n, N = 1 << logn, 1 << (logn + lb)
+            cols = rng.integers(0, p, (W, n), dtype=np.int64).astype(np.uint64)
+            toff, loff = int(rng.integers(1, p)), int(rng.integers(1, p))
+            d_cols, d_out = e.dev_alloc(W * n * 4), e.dev_alloc(W * N * 4)
+            e.dev_upload(cols.reshape(-1), d_cols)
+            e.dev_lde(d_cols, W, logn, lb, d_out, toff, loff)
+            got = e.dev_download(d_out, W * N).reshape(W, N)
+            w, Wn = o.ff_prim_nth_root_g(n, p, g), o.ff_prim_nth_root_g(N, p, g)
+            for c in rng.choice(W, 2, replace=False):
+                assert np.array_equal(got[c], o.fast_coset_ntt(o.fast_intt(cols[c], w, toff, p), N, Wn, loff, p)), ("lde columns", logn, lb, W, int(c))
+            e.dev_free(d_cols)
+            e.dev_free(d_out)
         else:
             continue
         n_cases += 1
