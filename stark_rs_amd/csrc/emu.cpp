@@ -57,6 +57,9 @@ template <int LOGR, int LOGW, int KIND, int CAP> void emu_pass_cols(const PassAr
         break;
                 switch (a.zlog) { ZCASE(2) ZCASE(3) ZCASE(4) default: ZCASE(0) }
 #undef ZCASE
+            } else if (a.flags & NTT_LAST_DIRECT) {
+                for (uint32_t tid = 0; tid < NT; tid++) NP::load_rows_direct(a, t, b, r16(regs[tid]), tid);
+                for (uint32_t tid = 0; tid < NT; tid++) NP::step0_rows(a, r16(regs[tid]), tile.data(), tw.data(), tid);
             } else {
                 for (uint32_t tid = 0; tid < NT; tid++) NP::load_rows(a, t, b, r16(regs[tid]), tid);
                 for (uint32_t tid = 0; tid < NT; tid++) NP::rows_to_lds(r16(regs[tid]), tile.data(), tid);
@@ -92,6 +95,10 @@ template <int LOGR, int LOGW, int KIND, int CAP> void emu_pass(const PassArgs &a
         break;
                 switch (a.zlog) { ZCASE(0) ZCASE(1) ZCASE(2) ZCASE(3) ZCASE(4) }
 #undef ZCASE
+            } else if (a.flags & NTT_LAST_DIRECT) {
+                std::vector<std::array<uint32_t, 16>> regs(NT);
+                for (uint32_t tid = 0; tid < NT; tid++) NP::load_rows_direct(a, t, b, reinterpret_cast<uint32_t(&)[16]>(regs[tid]), tid);
+                for (uint32_t tid = 0; tid < NT; tid++) NP::step0_rows(a, reinterpret_cast<uint32_t(&)[16]>(regs[tid]), tile.data(), tw.data(), tid);
             } else {
                 for (uint32_t tid = 0; tid < NT; tid++) {
                     uint32_t v[16];
@@ -140,6 +147,8 @@ struct EmuLauncher {
 
 }  // namespace
 
+static bool g_emu_last_direct = true;    // the product's default (internal.h)
+extern "C" void emu_set_last_direct(int on) { g_emu_last_direct = on != 0; }
 static int g_emu_defer_tw = 2;   // NttRequest::defer_tw: 0 never, 1 always, 2 the driver's rule
 extern "C" void emu_set_defer_tw(int mode) { g_emu_defer_tw = mode; }
 extern "C" void emu_set_share_cols(int mode) { g_share_cols = mode; }
@@ -179,6 +188,7 @@ extern "C" int emu_ntt(uint64_t p, uint64_t g, const uint32_t *in, uint32_t *out
     rq.in = in; rq.out = out; rq.scratch = scratch.data();
     rq.L = L; rq.n_in = n_in; rq.batch = batch; rq.in_stride = in_stride; rq.out_stride = out_stride; rq.F = F;
     rq.defer_tw = g_emu_defer_tw;
+    rq.last_direct = g_emu_last_direct;
     EmuLauncher ln;
     return ntt_run(ln, rq) ? 0 : -1;
 }

@@ -43,6 +43,7 @@ struct smi_ctx {
     // three-pass transforms: the second pass applies the first pass's inter-pass twiddle as it loads (ntt_core.h)
     bool ntt_share_cols = !(getenv("SMI_NTT_SHARE_COLS") && atoi(getenv("SMI_NTT_SHARE_COLS")) == 0);   // tuning knob, default on
     bool ntt_twin_regs = !(getenv("SMI_NTT_TWIN_REGS") && atoi(getenv("SMI_NTT_TWIN_REGS")) == 0);   // tuning knob, default on: deferred twiddles held as per-thread input multipliers
+    bool ntt_last_direct = !(getenv("SMI_NTT_LAST_DIRECT") && atoi(getenv("SMI_NTT_LAST_DIRECT")) == 0);   // NttRequest::last_direct; tuning knob, default on
     int ntt_defer_tw = getenv("SMI_NTT_DEFER_TW") ? (atoi(getenv("SMI_NTT_DEFER_TW")) != 0) : 2;   // NttRequest::defer_tw; tuning knob, default 2 (auto)
     bool lde_two_pass = getenv("SMI_LDE_TWO_PASS") && atoi(getenv("SMI_LDE_TWO_PASS"));   // smi_ctx_lde_two_pass
     std::vector<ProfRec> prof;

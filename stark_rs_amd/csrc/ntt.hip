@@ -37,6 +37,10 @@ __global__ __launch_bounds__(1 << (LOGR + LOGW - 4)) void ntt_pass_kernel(const 
         NP::template load_regs<0>(a, t, batch, v, tid);
         __syncthreads();
         NP::template step0_regs<0>(a, v, tile, tw, tid);
+    } else if (a.flags & NTT_LAST_DIRECT) {
+        NP::load_rows_direct(a, t, batch, v, tid);
+        __syncthreads(); /* twiddle table staged */
+        NP::step0_rows(a, v, tile, tw, tid);
     } else {
         NP::load_rows(a, t, batch, v, tid);
         NP::rows_to_lds(v, tile, tid);
@@ -104,6 +108,10 @@ __global__ __launch_bounds__(1 << (LOGR + LOGW - 4), TWIN ? SMI_COLS_TWIN_WAVES 
             }
             __syncthreads();
             NP::template step0_regs<0>(a, v, tile, tw, tid);
+        } else if (a.flags & NTT_LAST_DIRECT) {
+            NP::load_rows_direct(a, t, batch, v, tid);
+            __syncthreads();
+            NP::step0_rows(a, v, tile, tw, tid);
         } else {
             NP::load_rows(a, t, batch, v, tid);
             if (batch != col0) __syncthreads();
@@ -131,7 +139,8 @@ __global__ __launch_bounds__(1 << (LOGR + LOGW - 4)) void ntt_copy_probe_kernel(
     const typename NP::TileId t = NP::tile_id(a, blockIdx.x);
     uint32_t v[NP::V];
     if constexpr (KIND == PASS_LAST) {
-        NP::load_rows(a, t, batch, v, tid);
+        if (a.flags & NTT_LAST_DIRECT) NP::load_rows_direct(a, t, batch, v, tid);
+        else NP::load_rows(a, t, batch, v, tid);
     } else if constexpr (KIND == PASS_MID) {
         NP::template load_regs<0>(a, t, batch, v, tid);
     } else {
@@ -447,6 +456,7 @@ int dev_ntt(smi_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint32_t log_n,
         SMI_TRY(ctx_scale_tables(ctx, ninv, q, log_n, &rq.S));
     }
     rq.defer_tw = ctx->ntt_defer_tw;
+    rq.last_direct = ctx->ntt_last_direct;
     if (ntt_make_plan(log_n, batch).np > 0) SMI_TRY(ctx_scratch(ctx, (size_t)batch << log_n, &rq.scratch));   // inter-pass buffer
     HipLauncher ln{ctx};
     if (!ntt_run(ln, rq)) return smi_fail(ctx, SMI_ERR_BAD_ARG, "ntt: multi-pass plan without its inter-pass buffer");

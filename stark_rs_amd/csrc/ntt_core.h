@@ -60,7 +60,7 @@ struct ScaleTables {      // c * q^i = lo[i & (2^h-1)] * hi[i >> h]   (Montgomer
     const uint32_t *lo, *hi;
     uint32_t h;
 };
-enum { NTT_FIRST = 1, NTT_PRE_SCALE = 2, NTT_POST_SCALE = 4, NTT_TW_SKIP = 8, NTT_TW_IN = 16 };
+enum { NTT_FIRST = 1, NTT_PRE_SCALE = 2, NTT_POST_SCALE = 4, NTT_TW_SKIP = 8, NTT_TW_IN = 16, NTT_LAST_DIRECT = 32 };
 
 struct PassArgs {
     const uint32_t *in;
@@ -361,6 +361,47 @@ template <int LOGR, int LOGW, int KIND, int CAP> struct NttPass {
         for (int i = 0; i < V; i++) {
             const uint32_t idx = tid + i * NT;
             tile[(idx & (R - 1)) * WP + (idx >> LOGR)] = v[i];
+        }
+    }
+
+    // ---- last pass, NTT_LAST_DIRECT: step 0 on the registers the loads landed in, like the strided passes -- no
+    // transposition through LDS before the first butterflies (one LDS round trip and one barrier fewer).  A thread owns
+    // (pos, line) with pos the fastest index over the lanes, so its 16 loads are elements pos + q*R/16 of its line
+    // (R/16 consecutive elements per line and load instruction: 64-byte pieces at R = 256) and exactly the inputs of
+    // its radix-16 butterfly.  Lines are dealt to the lanes rotated by log2(R/16) bits so that the LDS writes of a
+    // half-wave (row stride WP = W + 1, bank = (pos + line) mod 32) fall into distinct banks.
+    static SMI_HD void direct_map(uint32_t tid, uint32_t &pos, uint32_t &line) {
+        enum { SUB = LOGR - 4, ROT = SUB >= 5 ? 0 : SUB % LOGW };
+        pos = tid & ((1u << SUB) - 1u);
+        const uint32_t lsel = tid >> SUB;
+        if constexpr (ROT != 0) line = ((lsel << ROT) | (lsel >> (LOGW - ROT))) & (W - 1);
+        else line = lsel;
+    }
+    static SMI_HD void load_rows_direct(const PassArgs &a, const TileId &t, uint32_t batch, uint32_t (&v)[V], uint32_t tid) {
+        enum { SUB = LOGR - 4 };
+        const uint32_t *in = a.in + (uint64_t)batch * a.in_stride + t.in_base;
+        const uint32_t arest_log = a.Sp - a.d0_log;
+        uint32_t pos, line;
+        direct_map(tid, pos, line);
+        const uint32_t o0 = (line << (arest_log + LOGR)) + pos;
+#pragma unroll
+        for (int i = 0; i < V; i++) v[i] = ld32(in, o0 + ((uint32_t)i << SUB));
+    }
+    static SMI_HD void step0_rows(const PassArgs &a, uint32_t (&x)[V], uint32_t *tile, const Tw2 *tw, uint32_t tid) {
+        enum { SUB = LOGR - 4 };
+        uint32_t pos, line;
+        direct_map(tid, pos, line);
+        int m[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) m[i] = 1;                      // canonical loads
+        dft_regs<4, CAP>(x, m, tw, LOGR - 4, a.F);
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) {
+            uint32_t v = x[brev<4>(kk)];
+            int mv = m[brev<4>(kk)];
+            if (kk) v = shoup_mul(v, tw[(pos * kk) & (R - 1)], a.F.p);
+            else lz_fold_to2(v, mv, a.F.p);
+            tile[(pos + ((uint32_t)kk << SUB)) * WP + line] = v;    // what step0_lds leaves: LDS holds [0,2p)
         }
     }
 

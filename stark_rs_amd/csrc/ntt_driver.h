@@ -18,6 +18,8 @@ struct NttRequest {
     bool pre_scale;      // multiply input i by S(i)   (coset shift of a forward transform)
     bool post_scale;     // multiply output k by S(k)  (n^-1 * offset^-k of an inverse transform)
     uint32_t q_plain;    // ratio of the scale sequence S(i) = c * q^i (plain form)
+    bool last_direct;    // the last pass runs its first radix-16 step on the load registers (NTT_LAST_DIRECT): one LDS round
+                         // trip fewer; 2^22 x 4 extension step 0.791 -> 0.779 ms over three A/B rounds (gpurun_out/exp_last_direct.log)
     int defer_tw;        // three or more passes: the first pass's inter-pass twiddle is applied by the second as it loads --
                          // 0 never, 1 always, 2 when the second pass takes the columns of a tile per workgroup (it then
                          // derives them once per thread for all of them, NttPass::in_mul: 2^25 x 4 first pass 199 -> 148 us,
@@ -55,6 +57,7 @@ template <class Launcher> inline bool ntt_run(Launcher &ln, const NttRequest &rq
         a.L = rq.L; a.Sp = consumed; a.n_in = rq.n_in;
         a.flags = (first ? NTT_FIRST : 0) | (first && rq.pre_scale ? NTT_PRE_SCALE : 0) |
                   (last && rq.post_scale ? NTT_POST_SCALE : 0);
+        if (last && rq.last_direct) a.flags |= NTT_LAST_DIRECT;
         if (defer && p == 0) a.flags |= NTT_TW_SKIP;
         if (defer && p == 1) {
             a.flags |= NTT_TW_IN;

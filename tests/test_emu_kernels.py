@@ -251,6 +251,34 @@ def test_emulated_ntt_deferred_first_twiddle(emu, oracle):
         emu.emu_set_share_cols(1)
 
 
+@pytest.mark.parametrize("direct", [1, 0])
+@pytest.mark.parametrize("p,g", [(P, G), (P2, G2)])
+@pytest.mark.parametrize("L", [13, 14, 15, 16, 17, 18, 19, 20])
+def test_emulated_ntt_last_pass_from_load_registers(emu, oracle, p, g, L, direct):
+    """NTT_LAST_DIRECT (csrc/ntt_core.h): the last pass runs its first radix-16 step on the registers its loads landed
+    in (lanes along a line, lines dealt to the lanes rotated) instead of transposing through LDS first -- every plan,
+    forward zero-padded and inverse with its output scale, one column and three (the column-sharing last pass); direct = 0
+    is the transposing load the knob SMI_NTT_LAST_DIRECT=0 (and the sharded transforms' remaining passes) keep."""
+    o = oracle
+    n = 1 << L
+    w = o.ff_prim_nth_root_g(n, p, g)
+    vals = o.splitmix64(100 + L, n) % np.uint64(p)
+    emu.emu_set_last_direct(direct)
+    emu.emu_set_share_cols(2)
+    try:
+        assert np.array_equal(_ntt(emu, p, g, vals, L, n, 1, 3), o.fast_intt(vals, w, 3, p))
+        nin = max(1, n // 8)
+        assert np.array_equal(_ntt(emu, p, g, vals[:nin], L, nin, 0, 3), o.fast_coset_ntt(vals[:nin], n, w, 3, p))
+        if L <= 17:
+            cols = [vals, np.full(n, p - 1, dtype=np.uint64), o.splitmix64(7 * L, n) % np.uint64(p)]
+            got = _ntt(emu, p, g, np.concatenate(cols), L, n, 1, 5, batch=3).reshape(3, n)
+            for c in range(3):
+                assert np.array_equal(got[c], o.fast_intt(cols[c], w, 5, p))
+    finally:
+        emu.emu_set_last_direct(1)
+        emu.emu_set_share_cols(1)
+
+
 @pytest.mark.parametrize("L,batch", [(14, 3), (17, 6), (21, 2)])
 def test_emulated_ntt_columns_of_a_tile_in_one_workgroup(emu, oracle, L, batch):
     """ntt_pass_cols_kernel (csrc/ntt.hip): with more than one column, a middle pass (and a last pass with an
