@@ -142,7 +142,7 @@ __global__ __launch_bounds__(1 << (LOGR + LOGW - 4)) void ntt_copy_probe_kernel(
         if (a.flags & NTT_LAST_DIRECT) NP::load_rows_direct(a, t, batch, v, tid);
         else NP::load_rows(a, t, batch, v, tid);
     } else if constexpr (KIND == PASS_MID) {
-        NP::template load_regs<0>(a, t, batch, v, tid);
+        NP::template load_regs<0, false>(a, t, batch, v, tid);   // the loads only, also when the pass applies deferred twiddles
     } else {
         switch (a.zlog) {
         case 2: NP::template load_regs<2>(a, t, batch, v, tid); break;
