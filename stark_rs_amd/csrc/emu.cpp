@@ -234,6 +234,7 @@ extern "C" int emu_ntt_shard_rest(uint64_t p, uint64_t g, uint32_t *rows, uint32
     EmuTables t;
     if (!emu_shard_request(p, g, L, inverse, 1, t)) return -1;
     t.rq.scratch = rows; t.rq.out = out;
+    t.rq.last_direct = g_emu_last_direct;
     EmuLauncher ln;
     return ntt_run_shard_rest(ln, t.rq, log_g) ? 0 : -1;
 }

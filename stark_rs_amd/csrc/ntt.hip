@@ -500,6 +500,7 @@ int dev_ntt_shard_rest(smi_ctx *ctx, uint32_t *d_rows, uint32_t *d_out, uint32_t
     NttRequest rq;
     SMI_TRY(shard_request(ctx, log_n, inverse, 1, &rq));
     rq.scratch = d_rows; rq.out = d_out;
+    rq.last_direct = ctx->ntt_last_direct;
     HipLauncher ln{ctx};
     if (!ntt_run_shard_rest(ln, rq, log_g)) return smi_fail(ctx, SMI_ERR_BAD_ARG, "sharded transform: size too small for this many ranks");
     if (ln.err != hipSuccess) return smi_hip_fail(ctx, ln.err, "ntt kernel launch");

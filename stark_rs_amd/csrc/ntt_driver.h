@@ -137,7 +137,7 @@ template <class Launcher> inline bool ntt_run_shard_rest(Launcher &ln, const Ntt
         a.in_stride = a.out_stride = nl;
         a.F = rq.F; a.T = rq.T; a.S = rq.S;
         a.L = Ll; a.Sp = consumed; a.n_in = (uint32_t)nl;
-        a.flags = last && rq.post_scale ? NTT_POST_SCALE : 0;
+        a.flags = (last && rq.post_scale ? NTT_POST_SCALE : 0) | (last && rq.last_direct ? NTT_LAST_DIRECT : 0);
         a.d0_log = (uint32_t)pl.logr[0] - log_g;
         a.n_mid = (uint32_t)(pl.np - 2);
         for (int d = 0; d < pl.np - 2; d++) a.mid_log[d] = (uint32_t)pl.logr[1 + d];

@@ -258,7 +258,7 @@ def test_emulated_ntt_last_pass_from_load_registers(emu, oracle, p, g, L, direct
     """NTT_LAST_DIRECT (csrc/ntt_core.h): the last pass runs its first radix-16 step on the registers its loads landed
     in (lanes along a line, lines dealt to the lanes rotated) instead of transposing through LDS first -- every plan,
     forward zero-padded and inverse with its output scale, one column and three (the column-sharing last pass); direct = 0
-    is the transposing load the knob SMI_NTT_LAST_DIRECT=0 (and the sharded transforms' remaining passes) keep."""
+    is the transposing load the knob SMI_NTT_LAST_DIRECT=0 keeps."""
     o = oracle
     n = 1 << L
     w = o.ff_prim_nth_root_g(n, p, g)
