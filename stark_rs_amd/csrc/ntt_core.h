@@ -86,7 +86,7 @@ struct PassArgs {
     // columns b in [b_off, b_off + B >> shard_log) of the pass's [R][B] view as a strip [R][B >> shard_log];
     // addresses use the strip's row length, twiddles / scales / padding the global index.
     uint32_t shard_log, b_off;
-    // NTT_TW_SKIP: this (first) pass stores its outputs canonical and leaves its inter-pass twiddle
+    // NTT_TW_SKIP: this (first) pass stores its outputs lazily reduced (below CAP * p) and leaves its inter-pass twiddle
     // w_m^(k b) to the next pass; NTT_TW_IN: this (middle) pass applies it to its loads -- the first pass
     // of an extension is bound by arithmetic, the middle one by memory.  prev_logr = log2 of the
     // previous pass's digit (k = sub-problem index mod 2^prev_logr).
@@ -492,10 +492,16 @@ template <int LOGR, int LOGW, int KIND, int CAP> struct NttPass {
                     // the thread's butterflies, see above).  A per-pass table of (w, Shoup quotient)
                     // pairs read with the data's coalescing saves 60 VALU ops per thread but triples
                     // the L2 -> L1 traffic of the pass; measured slower (2^25 x 4: 266 vs 247 us).
-                    if (a.flags & NTT_TW_SKIP) {   // the next pass multiplies as it loads
+                    if (a.flags & NTT_TW_SKIP) {
+                        // The next pass multiplies as it loads, by a Montgomery product that takes any operand below
+                        // 2^32 beside a canonical one (a * b < p * 2^32 <=> CAP * p < 2^32): the values go to the
+                        // pass-private intermediate as they are, below CAP * p, without the folds back to [0, p)
+                        // (up to six instructions per output at CAP = 8).
 #pragma unroll
-                        for (int kk = 0; kk < RL; kk++)
-                            st32(out, o0 + ((uint32_t)kk << (KSTEP_LOG + blog)), lz_canon_m(x[brev<SL>(kk)], m[brev<SL>(kk)], p));
+                        for (int kk = 0; kk < RL; kk++) {
+                            SMI_BOUND_CHECK(x[brev<SL>(kk)], m[brev<SL>(kk)], p);
+                            st32(out, o0 + ((uint32_t)kk << (KSTEP_LOG + blog)), x[brev<SL>(kk)]);
+                        }
                         continue;
                     }
                     uint32_t cur = base_run;
