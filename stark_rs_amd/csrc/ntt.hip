@@ -91,16 +91,8 @@ __global__ __launch_bounds__(1 << (LOGR + LOGW - 4), TWIN ? SMI_COLS_TWIN_WAVES 
         asm volatile("" : "+v"(tid));
         uint32_t v[NP::V];
         // the barrier after the loads also separates the previous column's LDS reads from this column's writes
-        if constexpr (KIND == PASS_FIRST) {
-#define ZCASE(Z)                                         \
-    case Z:                                              \
-        NP::template load_regs<Z>(a, t, batch, v, tid);  \
-        __syncthreads();                                 \
-        NP::template step0_regs<Z>(a, v, tile, tw, tid); \
-        break;
-            switch (a.zlog) { ZCASE(2) ZCASE(3) ZCASE(4) default: ZCASE(0) }
-#undef ZCASE
-        } else if constexpr (KIND == PASS_MID) {
+        static_assert(KIND != PASS_FIRST, "first passes keep one workgroup per (tile, column), NttPass::share_cols");
+        if constexpr (KIND == PASS_MID) {
             NP::template load_regs<0, !TWIN>(a, t, batch, v, tid);
             if constexpr (TWIN) {
 #pragma unroll
@@ -295,15 +287,17 @@ struct HipLauncher {
         note();
     }
     template <int LR, int LW, int KIND, int CAP> void launch(const PassArgs &a) {
-        if (ctx->ntt_share_cols && NttPass<LR, LW, KIND, CAP>::share_cols(a)) {
-            const dim3 grid(a.n_tiles, NttPass<LR, LW, KIND, CAP>::col_groups(a));
-            if (KIND == PASS_MID && (a.flags & NTT_TW_IN) && ctx->ntt_twin_regs)
-                ntt_pass_cols_kernel<LR, LW, KIND, CAP, KIND == PASS_MID><<<grid, 1 << (LR + LW - 4), 0, ctx->stream>>>(a);
-            else
-                ntt_pass_cols_kernel<LR, LW, KIND, CAP><<<grid, 1 << (LR + LW - 4), 0, ctx->stream>>>(a);
+        if constexpr (KIND != PASS_FIRST) {
+            if (ctx->ntt_share_cols && NttPass<LR, LW, KIND, CAP>::share_cols(a)) {
+                const dim3 grid(a.n_tiles, NttPass<LR, LW, KIND, CAP>::col_groups(a));
+                if (KIND == PASS_MID && (a.flags & NTT_TW_IN) && ctx->ntt_twin_regs)
+                    ntt_pass_cols_kernel<LR, LW, KIND, CAP, KIND == PASS_MID><<<grid, 1 << (LR + LW - 4), 0, ctx->stream>>>(a);
+                else
+                    ntt_pass_cols_kernel<LR, LW, KIND, CAP><<<grid, 1 << (LR + LW - 4), 0, ctx->stream>>>(a);
+                return;
+            }
         }
-        else
-            ntt_pass_kernel<LR, LW, KIND, CAP><<<dim3(a.n_tiles, a.batch), 1 << (LR + LW - 4), 0, ctx->stream>>>(a);
+        ntt_pass_kernel<LR, LW, KIND, CAP><<<dim3(a.n_tiles, a.batch), 1 << (LR + LW - 4), 0, ctx->stream>>>(a);
     }
     template <int LR, int LW> void launch_probe(int kind, const PassArgs &a) {
         const dim3 grid(a.n_tiles, a.batch);
