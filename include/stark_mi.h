@@ -92,6 +92,10 @@ typedef struct {
 } smi_kernel_time;
 int smi_ctx_profile(smi_ctx *ctx, int enable);
 int smi_ctx_profile_read(smi_ctx *ctx, smi_kernel_time *out, size_t cap, size_t *n);
+/* Restrict the brackets to launches whose kernel name contains name_part (NULL or "": all launches).  Bracketing every
+ * launch perturbs what it measures -- kernels no longer run back to back and the chip clocks higher -- so bench.py
+ * times its dominant kernel with only that kernel bracketed, inside an otherwise undisturbed loop. */
+int smi_ctx_profile_only(smi_ctx *ctx, const char *name_part);
 /* Measurement aid for the roofline leg: while enabled, every NTT pass launches its copy-only twin
  * (same tiles, same global loads and store addresses, no arithmetic) so that smi_ctx_profile
  * times what HBM delivers for each pass's access pattern.  Outputs are meaningless while it is

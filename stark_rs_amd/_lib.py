@@ -88,6 +88,7 @@ def lib():
         "smi_ctx_set_stream": (i32, [vp, vp]),
         "smi_ctx_sync": (i32, [vp]),
         "smi_ctx_profile": (i32, [vp, i32]),
+        "smi_ctx_profile_only": (i32, [vp, C.c_char_p]),
         "smi_ctx_copy_probe": (i32, [vp, i32]),
         "smi_ctx_lde_two_pass": (i32, [vp, i32]),
         "smi_ctx_profile_read": (i32, [vp, vp, sz, C.POINTER(sz)]),

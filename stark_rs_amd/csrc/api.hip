@@ -147,6 +147,13 @@ int smi_ctx_profile(smi_ctx *ctx, int enable) {
     ctx->prof_on = enable != 0;
     return SMI_OK;
 }
+int smi_ctx_profile_only(smi_ctx *ctx, const char *name_part) {
+    if (!ctx) return SMI_ERR_BAD_ARG;
+    if (name_part && strlen(name_part) >= sizeof ctx->prof_only) return smi_fail(ctx, SMI_ERR_BAD_ARG, "profile filter too long");
+    memset(ctx->prof_only, 0, sizeof ctx->prof_only);
+    if (name_part) memcpy(ctx->prof_only, name_part, strlen(name_part));
+    return SMI_OK;
+}
 int smi_ctx_lde_two_pass(smi_ctx *ctx, int enable) {
     if (!ctx) return SMI_ERR_BAD_ARG;
     ctx->lde_two_pass = enable != 0;

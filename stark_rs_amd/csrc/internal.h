@@ -1,5 +1,6 @@
 // internal.h -- context and helpers shared by the translation units of libstarkmi.so.
 #pragma once
+#include <string.h>
 #include <hip/hip_runtime.h>
 
 #include <stdlib.h>
@@ -39,6 +40,7 @@ struct smi_ctx {
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
     std::string err;
     bool prof_on = false;
+    char prof_only[56] = {0};   // smi_ctx_profile_only: bracket only launches whose name contains this (empty: all)
     bool copy_probe = false;       // smi_ctx_copy_probe: NTT passes launch their copy-only twins
     // three-pass transforms: the second pass applies the first pass's inter-pass twiddle as it loads (ntt_core.h)
     bool ntt_share_cols = !(getenv("SMI_NTT_SHARE_COLS") && atoi(getenv("SMI_NTT_SHARE_COLS")) == 0);   // tuning knob, default on
@@ -63,6 +65,7 @@ struct ProfScope {
     ProfRec r;
     bool on;
     ProfScope(smi_ctx *c, const char *name, double bytes) : ctx(c), on(c->prof_on) {
+        if (on && c->prof_only[0] && !strstr(name, c->prof_only)) on = false;
         if (!on) return;
         r.name = name;
         r.bytes = bytes;

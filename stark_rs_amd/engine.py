@@ -57,6 +57,11 @@ class Engine:
         """Bracket every hot-path kernel launch with HIP events on the context's stream."""
         self._ck(self.L.smi_ctx_profile(self.h, 1 if enable else 0))
 
+    def profile_only(self, name_part=None):
+        """Bracket only launches whose kernel name contains name_part (None: all): one kernel timed inside an otherwise
+        undisturbed loop."""
+        self._ck(self.L.smi_ctx_profile_only(self.h, name_part.encode() if name_part else None))
+
     def lde_two_pass(self, enable=True):
         """extensions of 2^20..2^22 rows in two passes over the outputs (csrc/lde_core.h) instead of three"""
         self._ck(self.L.smi_ctx_lde_two_pass(self.h, 1 if enable else 0))

@@ -356,6 +356,33 @@ def test_lde_with_the_columns_of_a_tile_in_one_workgroup(eng, eng2, oracle, whic
     e.dev_free(d_out)
 
 
+def test_profile_only_brackets_the_named_kernel_alone(eng2, oracle):
+    """smi_ctx_profile_only: bench.py times its dominant kernel with only that kernel bracketed"""
+    o = oracle
+    logn, lb, W = 18, 3, 2
+    n, N = 1 << logn, 1 << (logn + lb)
+    cols = np.stack([_vals(o, 77 + c, n, P2) for c in range(W)])
+    d_in = _upload(eng2, cols)
+    d_out = eng2.dev_alloc(W * N * 4)
+    eng2.profile(True)
+    eng2.dev_lde(d_in, W, logn, lb, d_out, 1, G2)
+    every = eng2.profile_read()
+    assert len(every) >= 2
+    one = sorted(every)[0]
+    eng2.profile_only(one)
+    eng2.dev_lde(d_in, W, logn, lb, d_out, 1, G2)
+    only = eng2.profile_read()
+    assert list(only) == [one] and only[one]["launches"] == every[one]["launches"]
+    eng2.profile_only(None)
+    eng2.dev_lde(d_in, W, logn, lb, d_out, 1, G2)
+    assert sorted(eng2.profile_read()) == sorted(every)
+    eng2.profile(False)
+    with pytest.raises(Exception):
+        eng2.profile_only("x" * 80)
+    eng2.dev_free(d_in)
+    eng2.dev_free(d_out)
+
+
 @pytest.mark.parametrize("which", ["ref_prime", "second_prime"])
 def test_stark_prove_column_openings(eng, eng2, oracle, which):
     """smi_stark_cfg.open_columns: the FRI proof bytes are unchanged, the appended openings are byte for byte
