@@ -57,6 +57,8 @@ enum {
     SMI_ERR_NON_CANONICAL = -51,      /* a field value >= p where the precondition forbids it (H6) */
     SMI_ERR_UNSUPPORTED_PRIME = -52,  /* p must be an odd prime < 2^30 with p-1 divisible by the sizes used */
     SMI_ERR_NOT_GEOMETRIC = -53,      /* domain is not offset*omega^k: caller must fall back to the CPU code */
+    SMI_ERR_COLUMNS_NOT_BOUND = -54,  /* smi_stark_verify on a proof made without open_columns: nothing in it refers to the
+                                         column roots, so it can only be checked as a FRI proof (smi_fri_verify) */
     /* runtime */
     SMI_ERR_HIP = -100,
     SMI_ERR_NO_DEVICE = -101,
@@ -215,7 +217,15 @@ int smi_fri_prove(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint64_t *codeword
  * reference panic (e.g. a last codeword whose length is not a power of two, src/merkle.rs:13-16) is that panic's
  * status.  pv_indices / pv_values (optional, 2*t entries each) receive the (index, value) pairs the reference
  * pushes to polynomial_values.  Leaf hashes and authentication paths are checked in device batches, the last
- * layer's degree by an inverse + forward NTT; SMI_ERR_NOT_GEOMETRIC if cfg's omega does not generate the domain. */
+ * layer's degree by an inverse + forward NTT; SMI_ERR_NOT_GEOMETRIC if cfg's omega does not generate the domain.
+ * Two deliberate differences from the reference on malformed proofs, both failing closed (a status, never accept):
+ *   - a last codeword whose length is not domain_length >> (rounds - 1) but whose Merkle root matches: the reference
+ *     runs its O(L^3) Lagrange interpolation over the (then repeating or truncated) point list and returns whatever
+ *     that gives or panics with "no inverse"; the NTT needs the points to be a whole coset, so this returns
+ *     SMI_ERR_NOT_GEOMETRIC;
+ *   - unreduced values (>= p) in a triple: the colinearity test uses the reference's own `(p + l - r) % p` in u128
+ *     (src/ff.rs:154-160) including its release-build wrap for r > p + l (a debug build of the reference panics
+ *     there), and the leaf is hashed from the raw u64, as in the reference. */
 int smi_fri_verify(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint8_t *proof, size_t proof_len, int *accept, uint64_t *pv_indices,
                    uint64_t *pv_values, size_t *n_pv);
 int smi_fri_run_num_codewords(const smi_fri_run *run, size_t *n);
@@ -299,29 +309,16 @@ typedef struct {
 int smi_dev_stark_prove(smi_ctx *ctx, const smi_stark_cfg *cfg, const uint32_t *d_trace_cols, uint8_t *column_roots,
                         uint8_t **proof, size_t *proof_len, uint64_t *top_indices, double *stage_ms);
 
-/* Verifier of smi_dev_stark_prove / smi_mgpu_stark_prove (column trees): Fri::verify of the leading objects on the
- * domain lde_offset * <w_N> and, with cfg->open_columns, the column openings -- every authentication path against
+/* Verifier of smi_dev_stark_prove / smi_mgpu_stark_prove (column trees, cfg->open_columns != 0): Fri::verify of the
+ * leading objects on the domain lde_offset * <w_N>, then the column openings -- every authentication path against
  * its column root (column_roots: n_cols x 32) and sum_c weight_c * col_c[a] against the layer-0 triple -- with
- * the weights re-derived from the column roots.  *accept as in smi_fri_verify. */
+ * the weights re-derived from the column roots.  *accept as in smi_fri_verify.  A proof made with open_columns == 0
+ * is exactly Fri::prove's bytes: no object in it refers to the column roots, so accepting it here would present a
+ * low-degree proof of an unrelated codeword as a proof about these columns.  The call therefore returns
+ * SMI_ERR_COLUMNS_NOT_BOUND (*accept = 0, nothing verified) when cfg->open_columns == 0; check such a proof
+ * with smi_fri_verify. */
 int smi_stark_verify(smi_ctx *ctx, const smi_stark_cfg *cfg, const uint8_t *column_roots, const uint8_t *proof, size_t proof_len,
                      int *accept);
-
-/* Four-step NTT building blocks for one transform sharded over G GPUs: one
- * process per GPU; the all-to-all between the two local steps belongs to the caller
- * (RCCL via torch.distributed -- stark_rs_amd/fourstep.py).  N = R*C points viewed as an
- * R x C row-major matrix x[r*C + c]; rank g owns columns c0 .. c0 + C/G, stored
- * column-major (each column R contiguous values).
- *   1. smi_dev_ntt(batch = C/G, log_n = log R, offset = offset^C) transforms every column;
- *   2. smi_dev_fourstep_twiddle_pack multiplies element (c, kr) by offset^c * w_N^(kr*c)
- *      (w_N^-1 when inverse) and writes it into the send layout [G][C/G][R/G]
- *      (destination rank = kr / (R/G));
- *   3. all-to-all; the receive buffer is the matrix [C][R/G] of this rank's row block;
- *   4. smi_dev_transpose to [R/G][C], smi_dev_ntt(batch = R/G, log_n = log C), and
- *      smi_dev_transpose back to [C][R/G]: row kc holds X[kc*R + g*R/G + i], i < R/G. */
-int smi_dev_fourstep_twiddle_pack(smi_ctx *ctx, const uint32_t *d_cols, uint32_t *d_send, uint32_t log_r, uint32_t log_c,
-                                  uint32_t c0, uint32_t n_local_cols, uint32_t n_ranks, int inverse, uint64_t offset);
-/* out[c*rows + r] = in[r*cols + c] for a rows x cols matrix of u32 (LDS-tiled). */
-int smi_dev_transpose(smi_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, size_t rows, size_t cols);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ---------------------------
  * Fri::commit / Fri::prove (src/fri.rs:105-156, 250-311) over ONE codeword sharded in contiguous

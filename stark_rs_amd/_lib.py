@@ -147,9 +147,6 @@ def lib():
         "smi_dev_fri_prove": (i32, [vp, C.POINTER(FriCfg), vp, sz, C.POINTER(vp), C.POINTER(sz), vp, C.POINTER(vp)]),
         "smi_dev_combine_columns": (i32, [vp, vp, C.c_uint32, sz, sz, vp, vp]),
         "smi_dev_stark_prove": (i32, [vp, C.POINTER(StarkCfg), vp, vp, C.POINTER(vp), C.POINTER(sz), vp, vp]),
-        "smi_dev_fourstep_twiddle_pack": (i32, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
-                                                i32, C.c_uint64]),
-        "smi_dev_transpose": (i32, [vp, vp, vp, sz, sz]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -41,6 +41,7 @@ const char *smi_status_string(int status) {
     case SMI_ERR_NON_CANONICAL: return "field value not canonical (>= p)";
     case SMI_ERR_UNSUPPORTED_PRIME: return "unsupported modulus for this size";
     case SMI_ERR_NOT_GEOMETRIC: return "domain is not offset*omega^k";
+    case SMI_ERR_COLUMNS_NOT_BOUND: return "proof has no column openings: it does not bind the column roots";
     case SMI_ERR_HIP: return "HIP runtime error";
     case SMI_ERR_NO_DEVICE: return "no usable HIP device";
     case SMI_ERR_OOM: return "out of memory";
@@ -1042,6 +1043,3 @@ void smi_merkle_free(smi_tree *t) {
     delete t;
 }
 void smi_free(void *p) { free(p); }
-
-// ------------------------------------------------------------------------- four-step pieces
-// See fourstep.hip

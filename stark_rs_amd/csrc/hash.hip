@@ -112,7 +112,6 @@ __global__ __launch_bounds__(SMI_HASH_THREADS) void merkle_sub_kernel(const uint
             }
         }
     } else if (FROM_ELEMS) {
-#pragma unroll
         for (uint32_t i = 0; i < per; i += 2) {
             uint32_t d0[8], d1[8];
             if (i + 1 < per) {
@@ -125,7 +124,6 @@ __global__ __launch_bounds__(SMI_HASH_THREADS) void merkle_sub_kernel(const uint
             }
         }
     } else {
-#pragma unroll
         for (uint32_t i = 0; i < per; i++) {
             const uint4 *src = nodes + 2 * (level_offset(n, lvl_in) + first + i);
             const uint4 a = src[0], b = src[1];
@@ -133,11 +131,9 @@ __global__ __launch_bounds__(SMI_HASH_THREADS) void merkle_sub_kernel(const uint
             for (int w = 0; w < 8; w++) stash[(i * 8 + w) * SMI_HASH_THREADS + tid] = w < 4 ? (&a.x)[w] : (&b.x)[w - 4];
         }
     }
-#pragma unroll
-    for (uint32_t j = 1; j <= K; j++) {
+    for (uint32_t j = 1; j <= K; j++) {   // K and per are run-time values down here (KT == 0): nothing to unroll
         const uint32_t cnt = per >> j;
         uint4 *dst = nodes + 2 * (level_offset(n, lvl_in + j) + (t << (K - j)));
-#pragma unroll
         for (uint32_t q = 0; q < cnt; q += 2) {
             uint32_t l0[8], r0[8], d0[8];
             get(2 * q, l0);

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(1 << (LOGR + LOGW - 4)) void ntt_pass_kernel(const 
 // middle pass): unbounded 81 VGPRs 229 us, 6 waves (73 VGPRs) 222 us, 8 waves (64 VGPRs, 8 spilled) 254 us; one
 // workgroup per (tile, column) 237 us.
 #ifndef SMI_COLS_WAVES
-#define SMI_COLS_WAVES(TILE_LOG) ((TILE_LOG) >= 14 ? 4 : 6)
+#define SMI_COLS_WAVES(TILE_LOG, LOGR) ((TILE_LOG) >= 14 || (LOGR) >= 11 ? 4 : ((LOGR) == 10 ? 5 : 6))   // what LDS and the allocator leave room for with 1024- and 2048-point lines
 #endif
 #ifndef SMI_COLS_TWIN_WAVES   // tuning builds: the bound and the companions of the variant that also holds input multipliers
 #define SMI_COLS_TWIN_WAVES 4
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(1 << (LOGR + LOGW - 4)) void ntt_pass_kernel(const 
 #define SMI_COLS_TWIN_MQ 1
 #endif
 template <int LOGR, int LOGW, int KIND, int CAP, bool TWIN = false>   // TWIN: the previous pass left its twiddles to this one (NTT_TW_IN)
-__global__ __launch_bounds__(1 << (LOGR + LOGW - 4), TWIN ? SMI_COLS_TWIN_WAVES : SMI_COLS_WAVES(LOGR + LOGW)) void ntt_pass_cols_kernel(const PassArgs a) {
+__global__ __launch_bounds__(1 << (LOGR + LOGW - 4), TWIN ? SMI_COLS_TWIN_WAVES : SMI_COLS_WAVES(LOGR + LOGW, LOGR)) void ntt_pass_cols_kernel(const PassArgs a) {
     typedef NttPass<LOGR, LOGW, KIND, CAP> NP;
     __shared__ uint32_t tile[NP::R * NP::WP];
     __shared__ Tw2 tw[NP::R];

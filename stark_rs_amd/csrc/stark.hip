@@ -168,13 +168,14 @@ int smi_dev_stark_prove(smi_ctx *ctx, const smi_stark_cfg *cfg, const uint32_t *
     fc.expansion_factor = 1ull << cfg->log_blowup;
     fc.num_colinearity_tests = cfg->num_colinearity_tests;
     std::vector<uint8_t> bytes;
+    // the column openings need the top-level indices whether or not the caller wants them back
+    std::vector<uint64_t> top_tmp(top_indices ? 0 : (size_t)cfg->num_colinearity_tests);
+    if (!top_indices && !top_tmp.empty()) top_indices = top_tmp.data();
     SMI_TRY(fri_run(ctx, &fc, d_cw, N, true, false, nullptr, &bytes, top_indices, nullptr, nullptr, nullptr, nullptr));
     mark(4);
     if (cfg->open_columns && !cfg->row_leaves && cfg->num_colinearity_tests) {
         // the top-level indices are on the host now (fri_run synchronised): one more small launch
         const uint32_t t = (uint32_t)cfg->num_colinearity_tests;
-        std::vector<uint64_t> top_tmp(t);
-        if (!top_indices) return smi_fail(ctx, SMI_ERR_BAD_ARG, "open_columns needs top_indices");
         std::vector<MgSide> sides(W);
         for (uint32_t c = 0; c < W; c++) {
             MgSide &sd = sides[c];

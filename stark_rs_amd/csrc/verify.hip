@@ -63,7 +63,9 @@ uint32_t ilog2(uint64_t n) {
     return l;
 }
 uint64_t mulm(uint64_t a, uint64_t b, uint64_t p) { return (uint64_t)((unsigned __int128)a * b % p); }
-uint64_t subm(uint64_t a, uint64_t b, uint64_t p) { return (a % p + p - b % p) % p; }
+// FiniteField::sub (src/ff.rs:154-160): `p + l - r` in u128, then `% p`; for an unreduced r > p + l a release build wraps
+// mod 2^128 before the reduction (a debug build panics) -- the oracle restates the release behaviour and so does this
+uint64_t subm(uint64_t a, uint64_t b, uint64_t p) { return (uint64_t)((((unsigned __int128)p + a) - b) % p); }
 uint64_t powm(uint64_t b, uint64_t e, uint64_t p) {
     uint64_t r = 1 % p;
     b %= p;
@@ -290,6 +292,10 @@ int smi_stark_verify(smi_ctx *ctx, const smi_stark_cfg *cfg, const uint8_t *colu
     *accept = 0;
     const uint32_t W = cfg->n_cols, logN = cfg->log_n + cfg->log_blowup;
     if (!W || W > 64 || cfg->row_leaves) return smi_fail(ctx, SMI_ERR_BAD_ARG, "stark_verify: 1..64 column trees");
+    // Without the column openings the proof is Fri::prove's bytes and nothing else: no relation to column_roots
+    // could be checked, so nothing is "verified" here (include/stark_mi.h).
+    if (!cfg->open_columns)
+        return smi_fail(ctx, SMI_ERR_COLUMNS_NOT_BOUND, "stark_verify: proof made without open_columns; use smi_fri_verify for the FRI part");
     if (cfg->log_blowup < 2) return smi_fail(ctx, SMI_ERR_EXPANSION_TOO_SMALL, nullptr);
     if (logN > ctx->fs.K) return smi_fail(ctx, ctx->fs.F.p == 998244353u ? SMI_ERR_ROOT_TOO_LARGE : SMI_ERR_UNSUPPORTED_PRIME, "LDE domain too large");
     const uint64_t p = ctx->fs.F.p, N = 1ull << logN, t = cfg->num_colinearity_tests;
@@ -304,7 +310,7 @@ int smi_stark_verify(smi_ctx *ctx, const smi_stark_cfg *cfg, const uint8_t *colu
     std::vector<uint64_t> top, ab;
     size_t used = 0;
     SMI_TRY(fri_verify_objs(ctx, fc, objs, accept, &top, nullptr, nullptr, &ab, &used));
-    if (!*accept || !cfg->open_columns) return SMI_OK;
+    if (!*accept) return SMI_OK;
     // ---- the column openings (mgpu_core.h layout): rows, then paths
     *accept = 0;
     const size_t rec = 9 + 8 * (size_t)W, prec = 9 + 32 * (size_t)logN, need = t * 2 * rec + t * W * 2 * prec;

@@ -379,13 +379,6 @@ class Engine:
             out["stage_ms"] = dict(zip(("lde", "commit", "combine", "fri"), [float(x) for x in stage]))
         return out
 
-    def dev_fourstep_twiddle_pack(self, d_cols, d_send, log_r, log_c, c0, n_local_cols, n_ranks, inverse=False, offset=1):
-        self._ck(self.L.smi_dev_fourstep_twiddle_pack(self.h, vp(d_cols), vp(d_send), log_r, log_c, c0, n_local_cols, n_ranks,
-                                                      1 if inverse else 0, offset))
-
-    def dev_transpose(self, d_in, d_out, rows, cols):
-        self._ck(self.L.smi_dev_transpose(self.h, vp(d_in), vp(d_out), rows, cols))
-
 
 class DeviceTree:
     """MerkleTree kept on the device (all levels, src/merkle.rs:4-8)."""

@@ -313,7 +313,7 @@ def test_hash_bytes_batch(eng, oracle):
 
 def test_dev_hash_bytes_transcript_on_device(eng, oracle):
     """smi_dev_hash_bytes: message and digest in device memory (the device-resident Fiat-Shamir
-    transcript of stark_rs_amd/sharded.py): digest of every prefix of a run of roots equals
+    transcript the multi-GPU loop keeps): digest of every prefix of a run of roots equals
     Hash::from_bytes, and its first 8 bytes are FiatShamir::challenge (src/fiat_shamir.rs:19-25)."""
     import torch
     o = oracle

@@ -70,31 +70,6 @@ def test_stark_prove_composition(eng, eng2, oracle, which):
     assert set(res["stage_ms"]) == {"lde", "commit", "combine", "fri"}
 
 
-def test_transpose_and_fourstep_world1(eng2, oracle):
-    import torch
-    from stark_rs_amd.fourstep import FourStepNTT, HipBackend
-    o = oracle
-    rng = np.random.default_rng(0)
-    a = rng.integers(0, 2 ** 31, (100, 333), dtype=np.int32)
-    x = torch.from_numpy(a).cuda()
-    y = torch.empty(333 * 100, dtype=torch.int32, device="cuda")
-    eng2.dev_transpose(x.data_ptr(), y.data_ptr(), 100, 333)
-    eng2.sync()
-    assert np.array_equal(y.cpu().numpy().reshape(333, 100), a.T)
-    for (lr, lc, offset, inverse) in [(8, 8, 1, False), (7, 9, 31, False), (9, 8, 1, True)]:
-        N = 1 << (lr + lc)
-        xs = _vals(o, 5, N, P2)
-        cols = xs.astype(np.uint32).reshape(1 << lr, 1 << lc).T.copy()      # column-major
-        t = torch.from_numpy(cols.reshape(-1).view(np.int32)).cuda()
-        fs = FourStepNTT(HipBackend(eng2), lr, lc, P2)
-        out = fs.forward(t, offset=offset, inverse=inverse)
-        eng2.sync()
-        got = out.cpu().numpy().view(np.uint32).reshape(1 << lc, 1 << lr).reshape(-1).astype(np.uint64)
-        w = o.ff_prim_nth_root_g(N, P2, G2)
-        want = o.fast_intt(xs, w, 1, P2) if inverse else o.fast_coset_ntt(xs, N, w, offset, P2)
-        assert np.array_equal(got, want)
-
-
 def test_copy_probe_twins_run_and_leave_the_engine_intact(eng, oracle):
     """smi_ctx_copy_probe (bench.py's pattern-copy roofline leg): every pass launches its copy-only
     twin under a name of its own; switching it off restores the transform."""
@@ -163,60 +138,6 @@ def test_stark_prove_row_leaves_variant(eng, oracle):
     want, want_top = o.fri_prove(cfg, np.array(cw, dtype=np.uint64))
     assert res["proof"] == want and res["top_indices"] == want_top and o.fri_verify(cfg, res["proof"])
     eng.dev_free(d_trace)
-
-
-@pytest.mark.parametrize("which", ["ref_prime", "second_prime"])
-def test_sharded_stark_prove_world1_equals_single_gpu_prove(eng, eng2, oracle, which):
-    """ShardedStarkProve with the HIP backend at world size 1 against smi_dev_stark_prove on the same
-    trace: same column roots, same proof bytes, same top-level indices (the multi-rank paths run over
-    gloo in tests/test_sharded_gloo.py)."""
-    from stark_rs_amd.sharded import HipShardBackend, ShardedStarkProve
-    o = oracle
-    e, p, g = (eng, P, G) if which == "ref_prime" else (eng2, P2, G2)
-    logn, lb, W, t = 12, 3, 4, 8
-    n, N = 1 << logn, 1 << (logn + lb)
-    cols = np.stack([_vals(o, 0x5354524B00 + c, n, p) for c in range(W)])
-    d = _upload(e, cols)
-    want = e.dev_stark_prove(d, W, logn, lb, t)
-    e.dev_free(d)
-    be = HipShardBackend(e)
-    sp = ShardedStarkProve(be, p, g, logn, lb, W, t, e.prim_nth_root(N))
-    roots, proof, top = sp.prove(be.tensor(cols.reshape(-1)))
-    assert roots == [bytes(r) for r in want["column_roots"]]
-    assert proof == want["proof"] and top == want["top_indices"]
-
-
-def test_sharded_commit_backend_world1(eng, oracle):
-    """stark_rs_amd/sharded.py with the HIP backend at world size 1 (the collectives are covered by
-    the gloo test): subtree kernel, device transcript hash and the shard fold entry point."""
-    from stark_rs_amd.sharded import HipShardBackend, ShardedFriCommit
-    o = oracle
-    n, exp, t, offset = 1 << 14, 8, 8, 3
-    omega = o.ff_prim_nth_root(n)
-    codeword = o.fast_coset_ntt(_vals(o, 5, n // exp), n, omega, offset)
-    be = HipShardBackend(eng)
-    roots, alphas, last = ShardedFriCommit(be, P, omega, offset, n, exp, t).commit(be.tensor(codeword))
-    wroots, walphas, wlast = o.fri_commit_trace(o.fri_cfg(omega, offset, n, exp, t), codeword)
-    assert roots == [bytes(r) for r in wroots] and alphas == walphas
-    assert np.array_equal(last.cpu().numpy().view(np.uint32).astype(np.uint64), wlast)
-
-
-def test_sharded_prove_backend_world1(eng, oracle):
-    """ShardedFriProve with the HIP backend at world size 1: resident trees, one device gather per
-    batch of openings, proof serialized by the host side -- byte for byte the oracle's proof and the
-    C ABI's own smi_fri_prove."""
-    from stark_rs_amd.sharded import HipShardBackend, ShardedFriProve
-    o = oracle
-    n, exp, t, offset = 1 << 14, 8, 8, 3
-    omega = o.ff_prim_nth_root(n)
-    codeword = o.fast_coset_ntt(_vals(o, 6, n // exp), n, omega, offset)
-    be = HipShardBackend(eng)
-    proof, top = ShardedFriProve(be, P, omega, offset, n, exp, t).prove(be.tensor(codeword))
-    cfg = o.fri_cfg(omega, offset, n, exp, t)
-    want, want_top = o.fri_prove(cfg, codeword)
-    assert proof == want and top == want_top
-    got2, top2 = eng.fri_prove(eng.fri_cfg(omega, offset, n, exp, t), codeword)
-    assert bytes(got2) == proof and list(top2) == top
 
 
 def test_cfg3_full_size_lde_and_commit_properties(eng, oracle):

@@ -104,22 +104,92 @@ def test_stark_verify(oracle, which):
     cols = np.stack([o.splitmix64(0x5354524B00 + c, n) % np.uint64(p) for c in range(W)])
     d = e.dev_alloc(W * n * 4)
     e.dev_upload(cols.reshape(-1), d)
-    for open_columns in (False, True):
-        res = e.dev_stark_prove(d, W, logn, lb, t, open_columns=open_columns)
-        roots = [bytes(r) for r in res["column_roots"]]
-        ok, why = e.stark_verify(res["proof"], roots, W, logn, lb, t, open_columns=open_columns)
-        assert ok, why
-        bad = bytearray(res["proof"])
-        bad[len(bad) // 3] ^= 4
-        assert not e.stark_verify(bytes(bad), roots, W, logn, lb, t, open_columns=open_columns)[0]
-        if open_columns:
-            bad = bytearray(res["proof"])
-            bad[-5] ^= 1                                                   # inside the last authentication path
-            assert not e.stark_verify(bytes(bad), roots, W, logn, lb, t, open_columns=True)[0]
-            assert not e.stark_verify(res["proof"], roots[1:] + roots[:1], W, logn, lb, t, open_columns=True)[0]
-            assert not e.stark_verify(res["proof"][:-1], roots, W, logn, lb, t, open_columns=True)[0]
+    # a proof without column openings is Fri::prove's bytes: nothing in it refers to the column roots, so
+    # smi_stark_verify refuses it with a status of its own instead of "accepting" a proof it cannot bind
+    res = e.dev_stark_prove(d, W, logn, lb, t, open_columns=False)
+    roots = [bytes(r) for r in res["column_roots"]]
+    with pytest.raises(s.StarkMiError) as ei:
+        e.stark_verify(res["proof"], roots, W, logn, lb, t, open_columns=False)
+    assert ei.value.status == -54 and "column" in str(ei.value)
+    N = n << lb
+    fcfg = e.fri_cfg(e.prim_nth_root(N), g, N, 1 << lb, t)
+    assert e.fri_verify(fcfg, res["proof"])[0]                       # ... it still is a valid FRI proof
+    res = e.dev_stark_prove(d, W, logn, lb, t, open_columns=True)
+    roots = [bytes(r) for r in res["column_roots"]]
+    ok, why = e.stark_verify(res["proof"], roots, W, logn, lb, t, open_columns=True)
+    assert ok, why
+    bad = bytearray(res["proof"])
+    bad[len(bad) // 3] ^= 4
+    assert not e.stark_verify(bytes(bad), roots, W, logn, lb, t, open_columns=True)[0]
+    bad = bytearray(res["proof"])
+    bad[-5] ^= 1                                                   # inside the last authentication path
+    assert not e.stark_verify(bytes(bad), roots, W, logn, lb, t, open_columns=True)[0]
+    assert not e.stark_verify(res["proof"], roots[1:] + roots[:1], W, logn, lb, t, open_columns=True)[0]
+    assert not e.stark_verify(res["proof"][:-1], roots, W, logn, lb, t, open_columns=True)[0]
+    # a proof made from OTHER columns is not accepted against these roots (and vice versa)
+    other = np.stack([o.splitmix64(0x77 + c, n) % np.uint64(p) for c in range(W)])
+    d2 = e.dev_alloc(W * n * 4)
+    e.dev_upload(other.reshape(-1), d2)
+    res2 = e.dev_stark_prove(d2, W, logn, lb, t, open_columns=True)
+    roots2 = [bytes(r) for r in res2["column_roots"]]
+    assert e.stark_verify(res2["proof"], roots2, W, logn, lb, t, open_columns=True)[0]
+    assert not e.stark_verify(res2["proof"], roots, W, logn, lb, t, open_columns=True)[0]
+    assert not e.stark_verify(res["proof"], roots2, W, logn, lb, t, open_columns=True)[0]
+    e.dev_free(d)
+    e.dev_free(d2)
+    e.close()
+
+
+def test_stark_prove_with_openings_does_not_need_the_callers_index_buffer(oracle):
+    """smi_dev_stark_prove(open_columns = 1, top_indices = NULL): legal like in every other configuration -- the
+    indices the openings need are kept internally (it used to fail with BAD_ARG after all the GPU work)."""
+    import ctypes as C
+    import stark_rs_amd as s
+    from stark_rs_amd import _lib
+    o = oracle
+    e = s.Engine(P, G, 0)
+    logn, lb, W, t = 8, 2, 3, 4
+    n = 1 << logn
+    cols = np.stack([o.splitmix64(0x99 + c, n) % np.uint64(P) for c in range(W)])
+    d = e.dev_alloc(W * n * 4)
+    e.dev_upload(cols.reshape(-1), d)
+    want = e.dev_stark_prove(d, W, logn, lb, t, open_columns=True)
+    cfg = _lib.StarkCfg(logn, lb, W, 0, 1, G, t, 1)
+    proof, plen = C.c_void_p(), C.c_size_t()
+    st = e.L.smi_dev_stark_prove(e.h, C.byref(cfg), C.c_void_p(d), None, C.byref(proof), C.byref(plen), None, None)
+    assert st == 0
+    got = C.string_at(proof, plen.value)
+    e.L.smi_free(proof)
+    assert got == want["proof"]
     e.dev_free(d)
     e.close()
+
+
+def test_fri_verify_documented_status_not_verdict_cases(eng, oracle):
+    """The two deviations include/stark_mi.h documents for malformed proofs.  (1) A last codeword of another
+    length whose root matches: the reference interpolates over a truncated / repeating point list (verdict or
+    "no inverse" panic); the NTT cannot, so the call returns SMI_ERR_NOT_GEOMETRIC -- a status, never accept.
+    (2) An unreduced triple value far above p: FiniteField::sub's u128 `p + l - r` wraps in a release build;
+    same arithmetic here, so verdict and reason equal the oracle's."""
+    import stark_rs_amd as s
+    o = oracle
+    n, exp, t, offset = 256, 8, 5, 17
+    omega, ocfg, proof = _proof(o, n, exp, t, offset, 5)
+    ecfg = eng.fri_cfg(omega, offset, n, exp, t)
+    R = o.fri_num_rounds(ocfg)
+    n_last = n >> (R - 1)
+    for new_len in (n_last // 2, n_last * 2):
+        last = np.zeros(new_len, dtype=np.uint64)                  # the zero polynomial: low degree on any domain
+        root = o.merkle_commit(o.leaf_hashes(last))
+        forged = proof[:33 * (R - 1)] + b"\x00" + bytes(root) + b"\x02" + int(new_len).to_bytes(8, "little") + last.tobytes()
+        with pytest.raises(s.StarkMiError) as ei:
+            eng.fri_verify(ecfg, forged)
+        assert ei.value.status == -53
+    objs_off = 33 * R + 9 + 8 * n_last
+    for which in (0, 1, 2):
+        bad = bytearray(proof)
+        bad[objs_off + 9 + 8 * which:objs_off + 17 + 8 * which] = (2 ** 64 - 1 - which).to_bytes(8, "little")
+        assert _agree(o, eng, ocfg, ecfg, bytes(bad)) is False
 
 
 def test_fri_verify_reports_the_first_failure_in_the_reference_order(eng, oracle):
