@@ -45,7 +45,10 @@ def splitmix64(seed, n):
 
 def cpu_baseline():
     """The reference's own CPU algorithms (oracle = op-for-op port; Rust toolchain absent) on a
-    bounded sample of the same path: Lagrange interpolate_domain + power-sum eval_domain."""
+    bounded sample of the same path: Lagrange interpolate_domain at n = 2^8 and 2^10 + power-sum
+    eval_domain, the n^3 / N*d fit through the measured points extrapolated (and labelled so) to the
+    sizes of BASELINE's configs, the oracle's radix-2 restatement as the fair algorithmic baseline,
+    and the commit side (MerkleTree::new, fold_codeword) -- SURVEY 8(d), BASELINE.md section 3."""
     from oracle import oracle as o
     o.build()
     p = o.P_REF
@@ -64,6 +67,32 @@ def cpu_baseline():
         t2 = time.perf_counter()
         t_int += t1 - t0
         t_ev += t2 - t1
+    # the second measured point of interpolate_domain (n = 2^8; repeated to get above timer noise) and of
+    # eval_domain (d = 2^8, N = 2^11): the exponents of the fit come from the two points, not from the model
+    n8, N8 = 1 << 8, 1 << 11
+    w8, W8 = o.ff_prim_nth_root(n8), o.ff_prim_nth_root(N8)
+    dom8 = [o.ff_exp(w8, k) for k in range(n8)]
+    dom8_big = [o.ff_mul(3, o.ff_exp(W8, k)) for k in range(N8)]
+    vals8 = splitmix64(0x5354524B00, n8) % np.uint64(p)
+    reps8 = 4
+    t0 = time.perf_counter()
+    for _ in range(reps8):
+        c8 = o.poly_interpolate_domain(dom8, vals8)
+    t1 = time.perf_counter()
+    for _ in range(reps8):
+        o.poly_eval_domain(c8, dom8_big)
+    t2 = time.perf_counter()
+    t_int8, t_ev8 = (t1 - t0) / reps8, (t2 - t1) / reps8
+    t_int10, t_ev10 = t_int / n_cols, t_ev / n_cols
+    import math
+    exp_int = math.log(t_int10 / t_int8) / math.log(n / n8)                   # ~3 for the O(n^3) Lagrange form
+    exp_ev = math.log(t_ev10 / t_ev8) / math.log((n * N) / (n8 * N8))         # ~1 in N*d
+    def extrap(log_rows, log_blowup=3):       # model: t_int ~ n^3, t_ev ~ N*d, anchored at the 2^10 point
+        nn, NN = 1 << log_rows, 1 << (log_rows + log_blowup)
+        ti = t_int10 * (nn / n) ** 3
+        te = t_ev10 * (nn * NN) / (n * N)
+        return {"rows": f"2^{log_rows}", "interpolate_domain_s": ti, "eval_domain_s": te,
+                "field_elements_per_s": (nn + NN) / (ti + te), "years": (ti + te) / 3.156e7, "extrapolated": True}
     # the fair algorithmic baseline: the oracle's radix-2 restatement, same arithmetic, 1 thread
     big = splitmix64(2, 1 << 20) % np.uint64(p)
     w20, w23 = o.ff_prim_nth_root(1 << 20), o.ff_prim_nth_root(1 << 23)
@@ -100,15 +129,80 @@ def cpu_baseline():
         pass
     return {
         "cpu_model": model, "host_cores": os.cpu_count(), "threads_used": 1,
-        "merkle_node_hashes_per_s": (m - 1) / (t6 - t5), "fold_elements_per_s": (m // 2) / (t7 - t6),
+        "merkle_node_hashes_per_s": (m - 1) / (t6 - t5), "merkle_mixes_per_s": 10.0 * (m - 1) / (t6 - t5),
+        "fold_elements_per_s": (m // 2) / (t7 - t6),
         "commit_sample": f"oracle MerkleTree::new over 2^18 digests ({t6 - t5:.2f}s), Fri::fold_codeword of 2^18 elements ({t7 - t6:.2f}s), 1 thread",
         "value": n_cols * (n + N) / (t_int + t_ev), "unit": "field-elements/s", "cores": 1, "kind": "port",
         "sample": f"LDE of {n_cols} columns of 2^10 rows at blowup 8: oracle interpolate_domain n=2^10 ({t_int:.2f}s) + eval_domain "
                   f"d=2^10,N=2^13 ({t_ev:.2f}s), single thread, same u128 % p arithmetic and O(n^3)/O(N*d) algorithms as the reference",
+        # the two measured sizes of SURVEY 8(d) and what the fit through them says about the configs' sizes
+        "measured": {"interpolate_domain_s": {"2^8": t_int8, "2^10": t_int10}, "eval_domain_s": {"d=2^8,N=2^11": t_ev8, "d=2^10,N=2^13": t_ev10},
+                     "fitted_exponent_interpolate_in_n": exp_int, "fitted_exponent_eval_in_N_times_d": exp_ev},
+        "extrapolation": {"model": "interpolate_domain ~ n^3 (src/univariate/interpolate.rs:21-42), eval_domain ~ N*d (eval.rs:6-21), "
+                                   "anchored at the measured 2^10 point; EXTRAPOLATED, not measured -- the reference algorithm is intractable there",
+                          "cfg2_cfg3_2^20_rows": extrap(20), "headline_2^22_rows": extrap(22)},
         "fast_ntt_value": ((1 << 20) + (1 << 23)) / (t4 - t3),
         "fast_ntt_sample": f"oracle radix-2 iNTT 2^20 + coset NTT 2^23, 1 thread ({t4 - t3:.2f}s)",
         "fast_ntt_all_cores_value": n_thr * ((1 << 20) + (1 << 23)) / (t9 - t8), "fast_ntt_all_cores": n_thr,
     }
+
+
+def hash_roofline(kernels, ceiling_mix_per_s, stage_ms, n_leaves, n_trees, pmc_name="merkle_sub_kernel<leaves> K=2"):
+    """The prove's own roofline (Merkle "reported against both HBM and VALU").  `kernels` = event-bracketed
+    per-kernel times of ONE prove (smi_ctx_profile), alg_mixes / alg_bytes as the library accounts them (9 mix_state per
+    8-byte leaf, 10 per node; 4 B read per leaf, 32 B written per digest); `ceiling_mix_per_s` = smi_ctx_mix_probe in
+    this run (the bare permutation, two hashes per lane: the integer-VALU ceiling of this formulation at the clock the
+    chip holds under that load); `stage_ms` = the un-instrumented prove's stage times (events between the stages only).
+    Bracketing every launch lets the chip clock higher than in the plain prove, so the dominant kernel's duration is
+    scaled to the plain prove's clock the way `roofline` does it for the LDE: x (stage sum / bracketed kernel sum)."""
+    hashk = {k: v for k, v in kernels.items() if v.get("alg_mixes", 0) > 0}
+    if not hashk or not ceiling_mix_per_s:
+        return None
+    dom_name, dom = max(hashk.items(), key=lambda kv: kv[1]["total_ms"])
+    bracketed_sum = sum(v["total_ms"] for v in kernels.values())
+    plain_sum = sum(stage_ms.values())
+    scale = max(1.0, plain_sum / bracketed_sum) if bracketed_sum > 0 else 1.0
+    dom_ms = dom["total_ms"] * scale
+    out = {
+        "bound": "valu", "kernel": dom_name, "unit": "mix_state/s",
+        "achieved": dom["alg_mixes"] / (dom_ms * 1e-3), "peak": ceiling_mix_per_s,
+        "frac": dom["alg_mixes"] / (dom_ms * 1e-3) / ceiling_mix_per_s,
+        "peak_source": "smi_ctx_mix_probe in this run: bare mix_state loop, two hashes per lane, 40 workgroups per CU, no memory traffic",
+        "launches_per_prove": dom["launches"], "kernel_ms_per_prove": dom_ms, "kernel_ms_per_prove_bracketed": dom["total_ms"],
+        "mixes_per_prove_in_kernel": dom["alg_mixes"],
+        "hbm": {"alg_bytes_per_prove_in_kernel": dom["alg_bytes"], "achieved": dom["alg_bytes"] / (dom_ms * 1e-3) / 1e9,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["alg_bytes"] / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        "share_of_prove_kernel_time": dom["total_ms"] / bracketed_sum if bracketed_sum else None,
+    }
+    # whole prove and its commit stage against the same two ceilings, on the un-instrumented clock
+    tot_mixes = sum(v["alg_mixes"] for v in hashk.values())
+    out["whole_prove"] = {"mixes": tot_mixes, "ms": plain_sum, "achieved": tot_mixes / (plain_sum * 1e-3),
+                          "frac": tot_mixes / (plain_sum * 1e-3) / ceiling_mix_per_s,
+                          "hash_kernel_share_of_kernel_time": sum(v["total_ms"] for v in hashk.values()) / bracketed_sum}
+    if "commit" in stage_ms and stage_ms["commit"] > 0:
+        cm = n_trees * (19.0 * n_leaves - 10.0)                      # SURVEY 8(d): N*9 + (N-1)*10 per tree
+        cb = n_trees * 68.0 * n_leaves                               # ... and ~68 N bytes per tree
+        out["commit"] = {"mixes": cm, "ms": stage_ms["commit"], "achieved": cm / (stage_ms["commit"] * 1e-3),
+                         "frac": cm / (stage_ms["commit"] * 1e-3) / ceiling_mix_per_s,
+                         "hbm_achieved": cb / (stage_ms["commit"] * 1e-3) / 1e9, "hbm_frac": cb / (stage_ms["commit"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    # VALU instructions per thread of the dominant kernel: SQ_INSTS_VALU / SQ_WAVES from the committed rocprofv3 --pmc
+    # summary (tools/profile_prove_valu.sh), beside what its mixes alone cost in this formulation
+    try:
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_prove_pmc.json")))
+        if files:
+            pm = json.load(open(files[-1]))
+            e = pm.get(pmc_name) or pm.get(dom_name)
+            if e:
+                out["valu_instr_per_thread"] = e["valu_insts_per_wave"]
+                out["valu_instr_source"] = os.path.relpath(files[-1], ROOT) + " (rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES, earlier run)"
+                out["valu_instr_of_the_mixes_alone"] = 56 * 88 + 10 * 102   # 4 leaves + 2 nodes two per state (88 per mix), 1 node alone (102)
+    except Exception:
+        pass
+    out["kernels"] = {k: {"launches": v["launches"], "ms_per_prove_bracketed": v["total_ms"], "mixes": v["alg_mixes"],
+                          "Gmix_per_s_bracketed": v["alg_mixes"] / (v["total_ms"] * 1e-3) / 1e9 if v["total_ms"] else None}
+                      for k, v in hashk.items()}
+    return out
 
 
 def main():
@@ -205,6 +299,26 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    # sustained: at least a second of back-to-back steps (the 20-step headline is ~15 ms, too short to say anything
+    # about the clocks the chip holds under its power limit): same loop, same brackets, reported beside the headline
+    sustained = None
+    if not args.in_loop_only:
+        n_sus = max(200, int(1.2 / max(elapsed / args.steps, 1e-6)))
+        barrier()
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for _ in range(n_sus):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        t_sus = time.perf_counter() - ts
+        if distributed:
+            tt = torch.tensor([t_sus], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_sus = float(tt.item())
+        sustained = {"steps": n_sus, "seconds": t_sus, "ms_per_step": 1e3 * t_sus / n_sus,
+                     "value": world * N_COLS * (n + N) * n_sus / t_sus,
+                     "ratio_to_headline_ms_per_step": (t_sus / n_sus) / (elapsed / args.steps)}
     # roofline: a second set of steps with a HIP-event bracket around every launch (on the
     # engine's stream), outside the headline timing
     prof_steps = max(5, min(args.steps, 20))
@@ -282,9 +396,11 @@ def main():
                 "alg_bytes_per_launch": bytes_per_launch,
                 # whole-LDE view: SURVEY 8(d) (12+4B)*n*4 cols algorithmic bytes over the step's kernel time
                 "step_alg_bytes": (12 + 4 * (1 << LOG_BLOWUP)) * n * N_COLS,
-                "step_achieved": (12 + 4 * (1 << LOG_BLOWUP)) * n * N_COLS / (ntt_ms * 1e-3) / 1e9,
-                # ... and against the headline's own clock: algorithmic bytes of a step / ms_per_step / peak
+                # one clock for both: the headline's un-instrumented ms_per_step (step_frac = step_achieved / peak)
+                "step_achieved": (12 + 4 * (1 << LOG_BLOWUP)) * n * N_COLS / (elapsed / args.steps) / 1e9,
                 "step_frac": (12 + 4 * (1 << LOG_BLOWUP)) * n * N_COLS / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                # the same bytes over the sum of the event-bracketed kernel durations of a step (a higher clock, see kernels_note)
+                "step_achieved_bracketed_kernel_sum": (12 + 4 * (1 << LOG_BLOWUP)) * n * N_COLS / (ntt_ms * 1e-3) / 1e9,
                 "step_traffic": step_traffic,
                 # the same launch as a pure copy (no arithmetic): the ceiling of this access pattern
                 "pattern_copy_GBps": (bytes_per_launch / (probe_ms[dom_name] * 1e-3) / 1e9) if dom_name in probe_ms else None,
@@ -302,6 +418,8 @@ def main():
                    "prime": p, "points_per_step_per_gpu": points_per_step, "parallelism": f"columns x{world} (no collective)"},
         "roofline": roofline,
     }
+    if sustained is not None:
+        result["sustained"] = sustained
 
     # The headline line must survive anything the extra legs do: a watchdog thread prints what has
     # been measured so far and exits NON-ZERO if an extra (e.g. a collective on a flaky peer) hangs;
@@ -329,6 +447,10 @@ def main():
             print(json.dumps(snap, default=str), flush=True)
         os._exit(3)
 
+    class SelfCheckFailed(Exception):
+        pass
+    selfcheck_failed = False
+
     watchdog = threading.Timer(420.0, _bail)
     watchdog.daemon = True
     watchdog.start()
@@ -352,6 +474,14 @@ def main():
             result["proofs_per_s"] = world * 1e3 / prove_ms
             result["prove_stage_ms"] = res["stage_ms"]
             result["prove_proof_bytes"] = len(res["proof"])
+            # the prove on its own roofline: integer VALU (in-run ceiling of the bare permutation) and HBM
+            enter("prove_roofline")
+            ceiling = eng.mix_probe(512)
+            eng.profile(True)
+            eng.dev_stark_prove(trace.data_ptr(), N_COLS, LOG_ROWS, LOG_BLOWUP, N_TESTS)
+            pk = eng.profile_read()
+            eng.profile(False)
+            result["prove_roofline"] = hash_roofline(pk, ceiling, res["stage_ms"], N, N_COLS)
         except Exception as e:  # reported, never hidden
             result["prove_error"] = str(e)
         # build-defined variant: one tree over the rows of the extended trace instead
@@ -384,8 +514,11 @@ def main():
                 e1.dev_ntt(y.data_ptr(), x.data_ptr(), 20)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t1
-            result["ntt_2p20"] = {"field_elements_per_s": 2 * reps * (1 << 20) / dt, "us_per_transform": 1e6 * dt / (2 * reps),
-                                  "prime": s.P_REF}
+            us20 = 1e6 * dt / (2 * reps)
+            result["ntt_2p20"] = {"field_elements_per_s": 2 * reps * (1 << 20) / dt, "us_per_transform": us20, "prime": s.P_REF,
+                                  # 8 n algorithmic bytes per transform; two launches of ~7 us each: latency, not bandwidth
+                                  "alg_bytes_per_transform": 8 << 20, "achieved_GBps": (8 << 20) / (us20 * 1e-6) / 1e9,
+                                  "frac": (8 << 20) / (us20 * 1e-6) / 1e9 / HBM_PEAK_GBS, "bound_note": "launch latency (two passes of one wave of workgroups each)"}
             # ---- BASELINE configs[2]: 2^20-row x 4-column trace, LDE at blowup 8 + Merkle commit, on the
             # reference prime (N = 2^23 is its largest domain); the stage times of the prove over it
             try:
@@ -394,8 +527,22 @@ def main():
                 for _ in range(2):
                     e1.dev_stark_prove(tr.data_ptr(), N_COLS, 20, LOG_BLOWUP, N_TESTS)
                 r3 = e1.dev_stark_prove(tr.data_ptr(), N_COLS, 20, LOG_BLOWUP, N_TESTS, timed=True)
-                result["cfg3_2p20x4_blowup8"] = {"prime": s.P_REF, "lde_ms": r3["stage_ms"]["lde"], "commit_ms": r3["stage_ms"]["commit"],
-                                                 "prove_ms": sum(r3["stage_ms"].values())}
+                c3 = {"prime": s.P_REF, "lde_ms": r3["stage_ms"]["lde"], "commit_ms": r3["stage_ms"]["commit"],
+                      "prove_ms": sum(r3["stage_ms"].values())}
+                n3 = 1 << 20
+                lde_bytes3 = (12 + 4 * (1 << LOG_BLOWUP)) * n3 * N_COLS                       # (12 + 4B) n per column
+                c3["lde_frac"] = lde_bytes3 / (c3["lde_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                ceil3 = e1.mix_probe(512)
+                e1.profile(True)
+                e1.dev_stark_prove(tr.data_ptr(), N_COLS, 20, LOG_BLOWUP, N_TESTS)
+                pk3 = e1.profile_read()
+                e1.profile(False)
+                hr3 = hash_roofline(pk3, ceil3, r3["stage_ms"], n3 << LOG_BLOWUP, N_COLS)
+                if hr3:
+                    c3["commit_frac_valu"] = hr3["commit"]["frac"]
+                    c3["commit_frac_hbm"] = hr3["commit"]["hbm_frac"]
+                    c3["prove_roofline"] = {k: hr3[k] for k in ("kernel", "achieved", "peak", "frac", "unit", "hbm", "whole_prove", "commit")}
+                result["cfg3_2p20x4_blowup8"] = c3
             except Exception as e:
                 result["cfg3_error"] = str(e)
             e1.close()
@@ -429,8 +576,14 @@ def main():
                 if why or backend == "nccl":
                     result["mgpu_rccl_unavailable"] = why or "communicator failed on another rank"
             omega = eng.prim_nth_root(1 << logN)
-            # self-check before anything is timed: the sharded proof of a 2^20-point codeword must be
-            # byte-identical to the single-GPU proof of the same codeword (rank 0 computes both)
+            coll_kind = "rccl (in-library)" if host is None else "host shim (staged through host memory)"
+            result["mgpu_collectives"] = coll_kind
+            # Self-checks before anything is timed (the first multi-GPU run on real links must not report numbers for
+            # wrong results): each compares a multi-GPU entry point with the single-GPU one on the same input, on every
+            # rank; a mismatch on ANY rank is recorded, every rank skips the multi-GPU legs, the headline line is still
+            # printed and the process exits non-zero at the end (never os._exit in the middle of a collective sequence).
+            checks = {}
+            # (1) Fri::prove of a 2^20-point codeword: sharded proof == single-GPU proof, byte for byte
             chk_n = 1 << 20
             chk = (splitmix64(11, chk_n) % np.uint64(p)).astype(np.uint32)
             cfg_c = eng.fri_cfg(eng.prim_nth_root(chk_n), s.G2, chk_n, 1 << LOG_BLOWUP, N_TESTS)
@@ -438,10 +591,43 @@ def main():
             got, got_top = mg.fri_prove(cfg_c, d_part.data_ptr(), chk_n // world)
             d_all = torch.from_numpy(chk.view(np.int32).copy()).to(dev)
             want = eng.dev_fri_prove(cfg_c, d_all.data_ptr(), chk_n)
-            if bytes(want[0]) != got or list(want[1]) != got_top:
-                print(f"bench.py: rank {rank}: sharded proof differs from the single-GPU proof", file=sys.stderr, flush=True)
-                os._exit(4)
-            result["mgpu_selfcheck"] = "sharded Fri::prove of a 2^20 codeword == single-GPU proof bytes on every rank"
+            checks["fri_prove_2p20"] = bytes(want[0]) == got and list(want[1]) == got_top
+            # (2) the sharded extension of a 2^18 x 4 trace: this rank's block of every column == the same block of smi_dev_lde
+            ln_c, n_c = 18, 1 << 18
+            N_c = n_c << LOG_BLOWUP
+            tr_c = torch.from_numpy(np.concatenate([(splitmix64(21 + c, n_c) % np.uint64(p)).astype(np.uint32) for c in range(N_COLS)]).view(np.int32)).to(dev)
+            ref_c = torch.empty(N_COLS * N_c, dtype=torch.int32, device=dev)
+            eng.dev_lde(tr_c.data_ptr(), N_COLS, ln_c, LOG_BLOWUP, ref_c.data_ptr())
+            blk_c = N_c // world
+            got_c = torch.empty(N_COLS * blk_c, dtype=torch.int32, device=dev)
+            mg.lde(tr_c.data_ptr(), N_COLS, ln_c, LOG_BLOWUP, got_c.data_ptr())
+            torch.cuda.synchronize()
+            checks["lde_2p18x4"] = bool(torch.equal(got_c.view(N_COLS, blk_c), ref_c.view(N_COLS, N_c)[:, rank * blk_c:(rank + 1) * blk_c]))
+            # (3) one 2^22-point transform over the ranks == smi_dev_ntt of the same input (natural order, this rank's block)
+            L_c = 22
+            x_c = (splitmix64(31, 1 << L_c) % np.uint64(p)).astype(np.uint32)
+            r0 = 1 << mg.ntt_first_digit(L_c)
+            B_c = (1 << L_c) // r0
+            strip_c = torch.from_numpy(np.ascontiguousarray(x_c.reshape(r0, B_c)[:, rank * (B_c // world):(rank + 1) * (B_c // world)]).reshape(-1).view(np.int32)).to(dev)
+            out_c = torch.empty((1 << L_c) // world, dtype=torch.int32, device=dev)
+            mg.ntt(strip_c.data_ptr(), out_c.data_ptr(), L_c, offset=s.G2, natural=True)
+            full_c = torch.from_numpy(x_c.view(np.int32).copy()).to(dev)
+            want_c = torch.empty_like(full_c)
+            eng.dev_ntt(full_c.data_ptr(), want_c.data_ptr(), L_c, offset=s.G2)
+            torch.cuda.synchronize()
+            per_c = (1 << L_c) // world
+            checks["ntt_2p22_natural_block"] = bool(torch.equal(out_c, want_c[rank * per_c:(rank + 1) * per_c]))
+            del tr_c, ref_c, got_c, strip_c, out_c, full_c, want_c, d_all, d_part
+            ok_all = torch.tensor([1 if all(checks.values()) else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
+            if not int(ok_all.item()):
+                bad = [k for k, v in checks.items() if not v]
+                result["mgpu_selfcheck"] = "MISMATCH" + (f" on this rank: {bad}" if bad else " on another rank")
+                print(f"bench.py: rank {rank}: multi-GPU self-check failed: {bad or 'another rank'}", file=sys.stderr, flush=True)
+                mg.close()
+                raise SelfCheckFailed()
+            result["mgpu_selfcheck"] = ("every rank: sharded Fri::prove of a 2^20 codeword == single-GPU proof bytes; smi_mgpu_lde 2^18 x 4 block == "
+                                        "smi_dev_lde; smi_mgpu_ntt 2^22 natural-order block == smi_dev_ntt")
             # BASELINE configs[3]: ONE 2^26-point transform over the N GPUs (strong scaling): pass 0 on column
             # strips, one all-to-all over xGMI, the remaining passes (smi_mgpu_ntt)
             enter("four_step_2p26")
@@ -466,7 +652,7 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             result["four_step_2p26"] = {"field_elements_per_s": reps * (1 << L26) / float(tt.item()),
                                         "ms_per_transform": 1e3 * float(tt.item()) / reps, "scaling": "strong",
-                                        "path": "pass pipeline + one all-to-all (smi_mgpu_ntt)"}
+                                        "path": "pass pipeline + one all-to-all (smi_mgpu_ntt)", "collectives": coll_kind}
             del strip, work, out26
             enter("mgpu fri / prove")
             # Fri::prove of one 2^25-point codeword
@@ -484,6 +670,7 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             result["sharded_fri_prove_2p25_ms"] = 1e3 * float(tt.item())
             result["sharded_fri_prove_bytes"] = len(proof)
+            result["sharded_fri_prove_collectives"] = coll_kind
             # BASELINE configs[4]: the full prove of ONE 2^22 x 4 trace over the N GPUs (strong scaling):
             # extension sharded by (column, coset) units, column trees and FRI by blocks of leaves
             one = torch.from_numpy(np.concatenate([(splitmix64(0x5354524B00 + c, n) % np.uint64(p)).astype(np.uint32)
@@ -500,15 +687,22 @@ def main():
             tt = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             result["sharded_prove_2p22x4_ms"] = {"value": 1e3 * float(tt.item()), "scaling": "strong", "proof_bytes": len(sproof),
-                                                 "collectives": "rccl (in-library)" if host is None else "host shim (staged through host memory)"}
+                                                 "collectives": coll_kind}
             mg.close()
+          except SelfCheckFailed:
+            selfcheck_failed = True
           except Exception as e:
             import traceback
             result["sharded_fri_error"] = f"{type(e).__name__}: {e} | {traceback.format_exc(limit=3)}"
 
+        # the CPU path beside the GPU numbers, at any world size: rank 0's host cores, one thread (the other ranks
+        # wait for it at the process group's teardown)
         enter("cpu_baseline")
-        if rank == 0 and world == 1:
-            result["cpu_baseline"] = cpu_baseline()
+        if rank == 0:
+            try:
+                result["cpu_baseline"] = cpu_baseline()
+            except Exception as e:
+                result["cpu_baseline_error"] = f"{type(e).__name__}: {e}"
 
     watchdog.cancel()
     if rank == 0:
@@ -516,6 +710,8 @@ def main():
     eng.close()
     if distributed:
         dist.destroy_process_group()
+    if selfcheck_failed:
+        sys.exit(4)
 
 
 if __name__ == "__main__":

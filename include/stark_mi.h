@@ -91,6 +91,8 @@ typedef struct {
     uint32_t launches;
     double total_ms;
     double alg_bytes;   /* algorithmic bytes summed over the launches (DESIGN.md states the per-unit figures) */
+    double alg_mixes;   /* hash kernels: mix_state evaluations (src/hash.rs:59-86) the launches' leaf and node hashes
+                           amount to -- 9 per 8-byte leaf, 10 per node (src/hash.rs:14-27,41-46); 0 elsewhere */
 } smi_kernel_time;
 int smi_ctx_profile(smi_ctx *ctx, int enable);
 int smi_ctx_profile_read(smi_ctx *ctx, smi_kernel_time *out, size_t cap, size_t *n);
@@ -103,6 +105,12 @@ int smi_ctx_profile_only(smi_ctx *ctx, const char *name_part);
  * times what HBM delivers for each pass's access pattern.  Outputs are meaningless while it is
  * on; never enable it in product use. */
 int smi_ctx_copy_probe(smi_ctx *ctx, int enable);
+/* Measurement aid for the prove's roofline (bench.py `prove_roofline`): the hash's permutation and nothing else --
+ * `mixes` back-to-back mix_state evaluations (src/hash.rs:59-86) per hash, two hashes per lane in the layout the
+ * Merkle kernels use, enough workgroups to fill the chip, no memory traffic -- timed with HIP events on the
+ * context's stream.  *mixes_per_s is the integer-VALU ceiling of this formulation of the hash on this GPU, at the
+ * clock the chip sustains under that load; the Merkle kernels are reported against it. */
+int smi_ctx_mix_probe(smi_ctx *ctx, uint32_t mixes, double *mixes_per_s);
 /* smi_dev_lde / smi_lde at 2^20..2^22 rows: run the extension in two passes over its outputs (coset-split
  * pass A, interleaving pass B -- csrc/lde_core.h) instead of the generic three.  Same results; off by
  * default (within 2 % of the generic path on MI355X); SMI_LDE_TWO_PASS=1 sets the default. */
@@ -371,6 +379,11 @@ int smi_mgpu_lde(smi_mgpu *m, const uint32_t *d_trace_cols, uint32_t n_cols, uin
  * Forward: evaluations on offset*<w_N>; inverse (offset must be 1): coefficients from values.  At G = 1 it is
  * the direct transform. */
 int smi_mgpu_ntt(smi_mgpu *m, uint32_t *d_strip, uint32_t *d_out, uint32_t log_n, int inverse, uint64_t offset);
+/* The same transform with the result as this rank's CONTIGUOUS natural-order block: d_out gets X[rank*N/G ..
+ * (rank+1)*N/G), the layout smi_mgpu_fri_commit / smi_mgpu_fri_prove take (so a 2^26-point evaluation can be
+ * committed without leaving the GPUs).  Costs a second all-to-all of the same volume: with one exchange the rank
+ * that owns k_0 holds every R_0-th output, and a contiguous output range is a range of the other index. */
+int smi_mgpu_ntt_natural(smi_mgpu *m, uint32_t *d_strip, uint32_t *d_out, uint32_t log_n, int inverse, uint64_t offset);
 int smi_mgpu_ntt_first_digit(uint32_t log_n, uint32_t *log_r0);
 /* smi_dev_stark_prove (column trees) over the G ranks: same column roots, same proof bytes. */
 int smi_mgpu_stark_prove(smi_mgpu *m, const smi_stark_cfg *cfg, const uint32_t *d_trace_cols, uint8_t *column_roots, uint8_t **proof,

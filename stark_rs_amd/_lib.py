@@ -9,6 +9,8 @@ import re
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# SMI_EMU_LIB: another build of the CPU emulator (tests only; the sanitizer build of `make asan`)
+EMU_PATH = os.environ.get("SMI_EMU_LIB") or os.path.join(_HERE, "build", "libstarkmi_emu.so")
 LIB_PATH = os.environ.get("SMI_LIB") or os.path.join(_HERE, "build", "libstarkmi.so")   # SMI_LIB: tuning builds
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "stark_mi.h")
 
@@ -29,7 +31,8 @@ class StarkMiError(RuntimeError):
 
 
 class KernelTime(C.Structure):
-    _fields_ = [("name", C.c_char * 56), ("launches", C.c_uint32), ("total_ms", C.c_double), ("alg_bytes", C.c_double)]
+    _fields_ = [("name", C.c_char * 56), ("launches", C.c_uint32), ("total_ms", C.c_double), ("alg_bytes", C.c_double),
+                ("alg_mixes", C.c_double)]
 
 
 class StarkCfg(C.Structure):
@@ -47,8 +50,10 @@ def build(force=False):
     """Compile libstarkmi.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     src_dir = os.path.join(_HERE, "csrc")
     srcs = [os.path.join(src_dir, f) for f in os.listdir(src_dir)] + [HEADER]
+    env = dict(os.environ)
+    env.pop("LD_PRELOAD", None)   # a sanitizer runtime preloaded into the test process must not reach the compilers
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "-j4"])
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-j4"], env=env)
     return LIB_PATH
 
 
@@ -90,6 +95,7 @@ def lib():
         "smi_ctx_profile": (i32, [vp, i32]),
         "smi_ctx_profile_only": (i32, [vp, C.c_char_p]),
         "smi_ctx_copy_probe": (i32, [vp, i32]),
+        "smi_ctx_mix_probe": (i32, [vp, C.c_uint32, C.POINTER(C.c_double)]),
         "smi_ctx_lde_two_pass": (i32, [vp, i32]),
         "smi_ctx_profile_read": (i32, [vp, vp, sz, C.POINTER(sz)]),
         "smi_ctx_modulus": (C.c_uint64, [vp]),

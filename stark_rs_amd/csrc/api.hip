@@ -188,6 +188,7 @@ int smi_ctx_profile_read(smi_ctx *ctx, smi_kernel_time *out, size_t cap, size_t 
         out[k].launches++;
         out[k].total_ms += ms;
         out[k].alg_bytes += r.bytes;
+        out[k].alg_mixes += r.mixes;
     }
     ctx->prof.clear();
     *n = cnt;
@@ -277,30 +278,42 @@ int ctx_root_table(smi_ctx *ctx, uint32_t log_m, const Tw2 **out) {
     *out = (const Tw2 *)ctx->d_root_tab[log_m];
     return SMI_OK;
 }
-// Makes room for `n` new entries NOW, so that the next n ctx_scale_tables calls cannot evict: a caller that
-// collects several tables before its launch (the fused FRI tail) would otherwise be left holding freed ones.
+// Makes room for `n` new entries: evicts the oldest unpinned entries (internal.h, ScaleScope) after draining the
+// stream -- in-flight kernels may still read them.  Entries looked up under the open scope stay; if everything is
+// pinned the cache simply grows past its soft cap.
 int ctx_scale_reserve(smi_ctx *ctx, size_t n) {
     if (ctx->scale_cache.size() + n < SMI_SCALE_CACHE_MAX) return SMI_OK;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // in-flight kernels may still read the ones dropped
-    size_t drop = ctx->scale_cache.size() / 2 > n ? ctx->scale_cache.size() / 2 : ctx->scale_cache.size();
-    if (drop > ctx->scale_cache.size()) drop = ctx->scale_cache.size();
-    for (size_t i = 0; i < drop; i++) {
-        (void)hipFree(ctx->scale_cache[i].lo);
-        (void)hipFree(ctx->scale_cache[i].hi);
+    auto pinned = [&](const ScaleEntry &e) { return ctx->scale_depth > 0 && e.epoch == ctx->scale_epoch; };
+    size_t want = ctx->scale_cache.size() / 2 > n ? ctx->scale_cache.size() / 2 : ctx->scale_cache.size();
+    bool any = false;
+    for (const ScaleEntry &e : ctx->scale_cache) any |= !pinned(e);
+    if (!any) return SMI_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<ScaleEntry> keep;
+    keep.reserve(ctx->scale_cache.size());
+    for (const ScaleEntry &e : ctx->scale_cache) {   // oldest first
+        if (want && !pinned(e)) {
+            (void)hipFree(e.lo);
+            (void)hipFree(e.hi);
+            want--;
+        } else {
+            keep.push_back(e);
+        }
     }
-    ctx->scale_cache.erase(ctx->scale_cache.begin(), ctx->scale_cache.begin() + (long)drop);
+    ctx->scale_cache.swap(keep);
     return SMI_OK;
 }
 int ctx_scale_tables(smi_ctx *ctx, uint32_t c_plain, uint32_t q_plain, uint32_t L, ScaleTables *out) {
-    for (const ScaleEntry &e : ctx->scale_cache)
+    for (ScaleEntry &e : ctx->scale_cache)
         if (e.c == c_plain && e.q == q_plain && e.L == L) {
+            e.epoch = ctx->scale_epoch;
             *out = ScaleTables{e.lo, e.hi, scale_table_h(L)};
             return SMI_OK;
         }
-    SMI_TRY(ctx_scale_reserve(ctx, 1));   // full: drops the oldest half (after draining the stream)
+    SMI_TRY(ctx_scale_reserve(ctx, 1));
     GeomSpec sp[2];
     scale_table_specs(ctx->fs.F, c_plain, q_plain, L, sp);
-    ScaleEntry e{c_plain, q_plain, L, nullptr, nullptr};
+    ScaleEntry e{c_plain, q_plain, L, nullptr, nullptr, ctx->scale_epoch};
     if (hipMalloc((void **)&e.lo, (size_t)sp[0].count * 4) != hipSuccess) return smi_fail(ctx, SMI_ERR_OOM, "hipMalloc scale table");
     if (hipMalloc((void **)&e.hi, (size_t)sp[1].count * 4) != hipSuccess) {
         (void)hipFree(e.lo);
@@ -641,6 +654,7 @@ int smi_poly_scale(smi_ctx *ctx, const uint64_t *coeffs, size_t n, uint64_t fact
     SMI_TRY(ctx_tmp(ctx, 0, n * 8, &stage));
     SMI_TRY(ctx_tmp(ctx, 1, n * 4, &d_in));
     SMI_TRY(ctx_tmp(ctx, 2, n * 4, &d_out));
+    ScaleScope pin__(ctx);
     ScaleTables S;
     SMI_TRY(ctx_scale_tables(ctx, 1, (uint32_t)factor, L, &S));
     HIP_TRY(ctx, hipMemcpyAsync(stage, coeffs, n * 8, hipMemcpyHostToDevice, ctx->stream));

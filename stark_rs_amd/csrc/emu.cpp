@@ -11,6 +11,7 @@
 #include "ntt_driver.h"
 #include "lde_core.h"
 #include "tables.h"
+#include "proof_parse.h"
 
 namespace {
 
@@ -465,4 +466,19 @@ extern "C" int emu_fold_shard(uint64_t p, uint64_t g, const uint32_t *lo, const 
     const uint32_t ah_m = fold_alpha_half(alpha, inv2_m, F);
     for (uint32_t i = 0; i < count; i++) out[i] = fold_element(lo[i], hi[i], i0 + i, ah_m, inv2_m, S, F);
     return 0;
+}
+
+// ProofStream::deserialize as smi_fri_verify runs it (csrc/proof_parse.h), exposed for the CPU fuzz / sanitizer
+// tests: tags, element counts and payload offsets of up to `cap` objects; returns how many objects there are.
+extern "C" size_t emu_proof_parse(const uint8_t *b, size_t n, size_t max_objs, int32_t *tags, uint64_t *counts, uint64_t *offsets,
+                                  size_t cap, size_t *end) {
+    size_t e = 0;
+    const std::vector<proofp::Obj> objs = proofp::parse(b, n, max_objs, &e);
+    for (size_t i = 0; i < objs.size() && i < cap; i++) {
+        tags[i] = objs[i].tag;
+        counts[i] = objs[i].count;
+        offsets[i] = (uint64_t)(objs[i].p - b);
+    }
+    if (end) *end = e;
+    return objs.size();
 }

@@ -132,6 +132,9 @@ struct EmuDev : MgDev {
                    uint64_t omega, uint32_t *out) override {
         return emu_fold_shard(p, g, lo, hi, (uint32_t)count, (uint32_t)i0, (uint32_t)full_len, *alpha, offset, omega, out) ? SMI_ERR_BAD_ARG : SMI_OK;
     }
+    // the loop's tail branch with the default per-round body (the product overrides fri_tail with one launch)
+    uint64_t tail_max_len() const override { return 512; }
+    uint32_t tail_max_rounds() const override { return 12; }
     int emit_codeword(const uint32_t *cw, uint64_t len, uint8_t *dst) override {   // src/fri.rs:151, src/stream.rs:48-53
         dst[0] = 2;
         mg_put_u64(dst + 1, len);
@@ -287,4 +290,10 @@ extern "C" int emu_mgpu_ntt(uint64_t p, uint64_t g, const smi_mgpu_coll *ops, in
     EmuDev d(p, g);
     EmuColl c(*ops);
     return mg_ntt(d, c, rank, world, strip, out, log_n, inverse, offset);
+}
+extern "C" int emu_mgpu_ntt_natural(uint64_t p, uint64_t g, const smi_mgpu_coll *ops, int rank, int world, uint32_t *strip, uint32_t *out,
+                                    uint32_t log_n, int inverse, uint64_t offset) {
+    EmuDev d(p, g);
+    EmuColl c(*ops);
+    return mg_ntt(d, c, rank, world, strip, out, log_n, inverse, offset, true);
 }

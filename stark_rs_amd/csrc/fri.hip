@@ -320,6 +320,7 @@ int launch_fold_shard(smi_ctx *ctx, const uint32_t *d_lo, const uint32_t *d_hi, 
     if (offset >= p || omega >= p) return smi_fail(ctx, SMI_ERR_NON_CANONICAL, "fold: offset/omega must be < p");
     if (offset == 0 || omega == 0) return smi_fail(ctx, SMI_ERR_DIV_BY_ZERO, "no division by zero");  // src/ff.rs:182
     if (!count) return SMI_OK;
+    ScaleScope pin__(ctx);
     ScaleTables S;
     SMI_TRY(ctx_scale_tables(ctx, h_inv(ctx, (uint32_t)offset), h_inv(ctx, (uint32_t)omega), ilog2(full_len / 2), &S));
     const uint32_t inv2_m = (uint32_t)(((uint64_t)h_inv(ctx, 2) << 32) % p);
@@ -363,6 +364,14 @@ static MiscLayout misc_layout(uint64_t R, uint64_t t) {
 
 // Fri::commit (+ optionally the query phase of Fri::prove) over a device codeword.
 // With do_query == false only roots/alphas/last codeword are produced.
+uint64_t fri_tail_len() {
+    static const uint64_t tail_len = [] {
+        const char *e = getenv("SMI_FRI_TAIL");
+        const uint64_t v = e ? (uint64_t)atoll(e) : 512;
+        return v > SMI_FRI_TAIL_MAX_LEN ? (uint64_t)SMI_FRI_TAIL_MAX_LEN : v;
+    }();
+    return tail_len;
+}
 int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, size_t len, bool do_query, bool reset_arena,
                    smi_fri_run **run_out, std::vector<uint8_t> *proof_host, uint64_t *top_host, uint8_t *roots_host,
                    uint64_t *alphas_host, uint64_t *last_host, size_t *last_len) {
@@ -380,6 +389,7 @@ int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, si
         if (t > last_n) return smi_fail(ctx, SMI_ERR_SAMPLE_TOO_MANY, "cannot sample more indices than available in last codeword");
     }
 
+    ScaleScope pin__(ctx);   // the fused tail collects one x^-1 table per fold before its single launch
     smi_fri_run *run = new smi_fri_run();
     run->ctx = ctx;
     run->owns_first = false;
@@ -433,11 +443,7 @@ int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, si
     // overhead.  Default: 512, the size the per-round path hands to a single workgroup anyway (above it
     // the per-round path spreads a tree's 64-leaf chunks over several CUs).  SMI_FRI_TAIL=<len> overrides
     // (0: never).
-    static const uint64_t tail_len = [] {
-        const char *e = getenv("SMI_FRI_TAIL");
-        const uint64_t v = e ? (uint64_t)atoll(e) : 512;
-        return v > SMI_FRI_TAIL_MAX_LEN ? (uint64_t)SMI_FRI_TAIL_MAX_LEN : v;
-    }();
+    const uint64_t tail_len = fri_tail_len();
     for (uint64_t r = 0; r < R; r++) {
         if (cur_len <= tail_len && R - r <= SMI_FRI_TAIL_MAX_ROUNDS) {
             // every remaining round in one workgroup launch (hash.hip, fri_tail_kernel)

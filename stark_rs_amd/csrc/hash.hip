@@ -299,7 +299,9 @@ __global__ __launch_bounds__(SMI_TOP_THREADS) void fri_tail_kernel(const FriTail
 int launch_fri_tail(smi_ctx *ctx, const FriTailArgs &a) {
     if (!a.n_rounds) return SMI_OK;
     if (a.n_rounds > SMI_FRI_TAIL_MAX_ROUNDS || a.r[0].len > SMI_TOP_MAX) return smi_fail(ctx, SMI_ERR_BAD_ARG, "fri tail: too long");
-    ProfScope ps(ctx, "fri_tail_kernel", 0.0);
+    double tail_mixes = 0.0;   // per round: len leaves, len - 1 nodes (the Fiat-Shamir hashes are not counted)
+    for (uint32_t k = 0; k < a.n_rounds; k++) tail_mixes += 9.0 * a.r[k].len + 10.0 * ((double)a.r[k].len - 1.0);
+    ProfScope ps(ctx, "fri_tail_kernel", 0.0, tail_mixes);
     fri_tail_kernel<<<1, SMI_TOP_THREADS, 0, ctx->stream>>>(a);
     HIP_TRY(ctx, hipGetLastError());
     return SMI_OK;
@@ -381,6 +383,43 @@ __global__ __launch_bounds__(64) void hash_bytes_batch_kernel(const uint8_t *msg
     uint32_t d[8];
     hashc::hash_bytes(msgs + i * len, len, d);
     for (int k = 0; k < 8; k++) out[8 * i + k] = d[k];
+}
+
+// smi_ctx_mix_probe: the bare permutation, two hashes per lane (State2), nothing else -- the ceiling the Merkle
+// kernels are reported against (bench.py prove_roofline).  The state is seeded per lane and folded into one
+// word at the end so that nothing is optimised away.
+__global__ __launch_bounds__(SMI_HASH_THREADS) void mix_probe_kernel(uint32_t *out, uint32_t mixes) {
+    hashc::State2 st;
+#pragma unroll
+    for (int w = 0; w < 32; w++) st.s[w] = (threadIdx.x * 2654435761u + (uint32_t)w * 40503u + blockIdx.x) & 0x00FF00FFu;
+#pragma unroll 1
+    for (uint32_t i = 0; i < mixes; i++) hashc::mix2_t<true>(st);
+    uint32_t x = 0;
+#pragma unroll
+    for (int w = 0; w < 32; w++) x ^= st.s[w];
+    out[(size_t)blockIdx.x * SMI_HASH_THREADS + threadIdx.x] = x;
+}
+int smi_ctx_mix_probe(smi_ctx *ctx, uint32_t mixes, double *mixes_per_s) {
+    if (!ctx || !mixes_per_s || !mixes) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(ctx);
+    const uint32_t blocks = (uint32_t)ctx->num_cus * 40;          // 40 workgroups per CU: several full waves of the chip
+    void *d_out = nullptr;
+    SMI_TRY(ctx_tmp(ctx, 3, (size_t)blocks * SMI_HASH_THREADS * 4, &d_out));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(ctx, hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return smi_fail(ctx, SMI_ERR_HIP, "hipEventCreate"); }
+    mix_probe_kernel<<<blocks, SMI_HASH_THREADS, 0, ctx->stream>>>((uint32_t *)d_out, mixes);   // warm-up (clocks, code)
+    (void)hipEventRecord(e0, ctx->stream);
+    mix_probe_kernel<<<blocks, SMI_HASH_THREADS, 0, ctx->stream>>>((uint32_t *)d_out, mixes);
+    (void)hipEventRecord(e1, ctx->stream);
+    const hipError_t err = hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (err != hipSuccess || hipGetLastError() != hipSuccess || ms <= 0.f) return smi_fail(ctx, SMI_ERR_HIP, "mix probe");
+    *mixes_per_s = 2.0 * (double)blocks * SMI_HASH_THREADS * (double)mixes / ((double)ms * 1e-3);
+    return SMI_OK;
 }
 
 // ------------------------------------------------------------------------- launches
@@ -496,7 +535,11 @@ static int launch_merkle_impl(smi_ctx *ctx, const uint32_t *d_elems, size_t n, u
         const size_t n_chunks = count / chunk;
         if (chunk <= SMI_TOP_MAX && n_chunks * n_trees <= TOP_BLOCKS) {
             const double hashed = (from_elems ? 2.0 * (double)count : (double)count) - (double)n_chunks;
-            ProfScope ps(ctx, "merkle_top_kernel", ((from_elems ? 4.0 * (row_cols ? row_cols : 1) : 32.0) * (double)count + 32.0 * hashed) * n_trees);
+            // mix_state evaluations: 9 per single-element leaf (one more per extra 32-byte chunk of a row), 10 per node
+            const double leaf_mixes = 8.0 + (row_cols ? (double)((row_cols + 3) / 4) : 1.0);
+            const double mixes = (from_elems ? leaf_mixes * (double)count : 0.0) + 10.0 * ((double)count - (double)n_chunks);
+            ProfScope ps(ctx, "merkle_top_kernel", ((from_elems ? 4.0 * (row_cols ? row_cols : 1) : 32.0) * (double)count + 32.0 * hashed) * n_trees,
+                         mixes * n_trees);
             const dim3 grid((uint32_t)n_chunks, n_trees);
             TopHook h{nullptr, nullptr, nullptr};
             if (hook && n_chunks == 1 && n_trees == 1) {   // this launch ends with the root
@@ -520,8 +563,10 @@ static int launch_merkle_impl(smi_ctx *ctx, const uint32_t *d_elems, size_t n, u
         const size_t lds = (size_t)(8u << K) * SMI_HASH_THREADS * sizeof(uint32_t);
         // algorithmic bytes: inputs read once (4 B elements or 32 B digests), every produced digest written once
         const double produced = from_elems ? (double)count * 2.0 - (double)(count >> K) : (double)count - (double)(count >> K);
+        const double sub_mixes = (from_elems ? (8.0 + (row_cols ? (double)((row_cols + 3) / 4) : 1.0)) * (double)count : 0.0) +
+                                 10.0 * ((double)count - (double)(count >> K));
         ProfScope ps(ctx, from_elems ? "merkle_sub_kernel<leaves>" : "merkle_sub_kernel<digests>",
-                     ((from_elems ? 4.0 * (row_cols ? row_cols : 1) : 32.0) * (double)count + 32.0 * produced) * n_trees);
+                     ((from_elems ? 4.0 * (row_cols ? row_cols : 1) : 32.0) * (double)count + 32.0 * produced) * n_trees, sub_mixes * n_trees);
         const dim3 grid(blocks_for(threads), n_trees);
         // the hot shapes (element leaves or digests, two levels per lane) have instantiations of their own
         static const bool generic_only = getenv("SMI_MERKLE_GENERIC") && atoi(getenv("SMI_MERKLE_GENERIC"));

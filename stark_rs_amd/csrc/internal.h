@@ -14,12 +14,14 @@
 struct ScaleEntry {
     uint32_t c, q, L;
     uint32_t *lo, *hi;
+    uint64_t epoch;   // smi_ctx::scale_epoch of the last ScaleScope that looked it up (pinned while that scope is open)
 };
 
 struct ProfRec {
     const char *name;
     hipEvent_t e0, e1;
     double bytes;
+    double mixes;   // hash kernels: mix_state evaluations of the launch (smi_kernel_time::alg_mixes)
 };
 
 struct smi_ctx {
@@ -30,6 +32,8 @@ struct smi_ctx {
     FieldSetup fs;
     uint32_t *d_tab[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};  // [dir][tw10, lo, hi]
     std::vector<ScaleEntry> scale_cache;
+    uint64_t scale_epoch = 1;   // bumped when an outermost ScaleScope opens
+    int scale_depth = 0;        // open ScaleScopes (they nest: stark_prove -> fri_run -> fold)
     uint32_t *d_root_tab[32] = {};   // [log m]: w_m^e, e < m, as (value, Shoup quotient) pairs (ctx_root_table)
     uint32_t *scratch = nullptr;   // NTT inter-pass buffer
     size_t scratch_elems = 0;
@@ -64,11 +68,12 @@ struct ProfScope {
     smi_ctx *ctx;
     ProfRec r;
     bool on;
-    ProfScope(smi_ctx *c, const char *name, double bytes) : ctx(c), on(c->prof_on) {
+    ProfScope(smi_ctx *c, const char *name, double bytes, double mixes = 0.0) : ctx(c), on(c->prof_on) {
         if (on && c->prof_only[0] && !strstr(name, c->prof_only)) on = false;
         if (!on) return;
         r.name = name;
         r.bytes = bytes;
+        r.mixes = mixes;
         if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) { on = false; return; }
         (void)hipEventRecord(r.e0, ctx->stream);
     }
@@ -123,8 +128,21 @@ NttTables ctx_tables(const smi_ctx *ctx, int inverse);
 // device table of w_m^e, e < m = 2^log_m (forward root), as Tw2 pairs; cached per log_m (log_m <= 17)
 int ctx_root_table(smi_ctx *ctx, uint32_t log_m, const Tw2 **out);
 int ctx_scale_tables(smi_ctx *ctx, uint32_t c_plain, uint32_t q_plain, uint32_t L, ScaleTables *out);
-#define SMI_SCALE_CACHE_MAX 96
-int ctx_scale_reserve(smi_ctx *ctx, size_t n);   // room for n more entries without an eviction in between
+#define SMI_SCALE_CACHE_MAX 96   // soft cap: entries pinned by an open ScaleScope are never evicted, the cache grows instead
+int ctx_scale_reserve(smi_ctx *ctx, size_t n);   // room for n more entries (evicts unpinned ones only)
+// Pins every scale table looked up while it is open: ctx_scale_tables hands out raw device pointers, and a caller
+// that holds one (or collects several, like the fused FRI tail) across another lookup must not see it freed by
+// that lookup's eviction.  Open one in every function that takes tables and enqueues the launches that read
+// them; an eviction drains the stream before it frees, so a table is safe once its launch is enqueued.
+struct ScaleScope {
+    smi_ctx *c;
+    explicit ScaleScope(smi_ctx *ctx) : c(ctx) {
+        if (c->scale_depth++ == 0) c->scale_epoch++;
+    }
+    ~ScaleScope() { c->scale_depth--; }
+    ScaleScope(const ScaleScope &) = delete;
+    ScaleScope &operator=(const ScaleScope &) = delete;
+};
 
 // field helpers on the host (plain form)
 inline uint32_t h_mul(const smi_ctx *c, uint32_t a, uint32_t b) { return host_mulmod(a, b, c->fs.F.p); }
@@ -156,6 +174,7 @@ struct FriTailArgs {
     uint32_t inv2_m;
 };
 int launch_fri_tail(smi_ctx *ctx, const FriTailArgs &a);
+uint64_t fri_tail_len();   // codewords of at most this many elements finish in the fused tail (SMI_FRI_TAIL, default 512; fri.hip)
 
 // launches (defined in the .hip files)
 int launch_geom_table(smi_ctx *ctx, const GeomSpec &s, uint32_t *d_out);

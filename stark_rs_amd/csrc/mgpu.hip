@@ -124,6 +124,32 @@ struct HipDev : MgDev {
                    uint64_t omega, uint32_t *out) override {
         return launch_fold_shard(ctx, lo, hi, count, i0, full_len, alpha, offset, omega, out);
     }
+    // the replicated rounds' tail in ONE workgroup launch, as in the single-GPU fri_run (csrc/hash.hip, fri_tail_kernel)
+    uint64_t tail_max_len() const override { return fri_tail_len(); }
+    uint32_t tail_max_rounds() const override { return SMI_FRI_TAIL_MAX_ROUNDS; }
+    int fri_tail(const MgTailRound *rounds, uint32_t n_rounds, void *fs) override {
+        if (!n_rounds) return SMI_OK;
+        ScaleScope pin__(ctx);   // one x^-1 table per fold, all held until the single launch
+        FriTailArgs ta;
+        memset(&ta, 0, sizeof ta);
+        ta.n_rounds = n_rounds;
+        ta.fs_words = (uint32_t *)fs;
+        ta.F = ctx->fs.F;
+        ta.inv2_m = (uint32_t)(((uint64_t)h_inv(ctx, 2) << 32) % ctx->fs.F.p);
+        for (uint32_t k = 0; k < n_rounds; k++) {
+            const MgTailRound &t = rounds[k];
+            FriTailRound &tr = ta.r[k];
+            tr.cw = t.cw; tr.next = t.next; tr.nodes = t.nodes; tr.proof_slot = t.proof_slot; tr.alpha_out = t.alpha_out;
+            tr.len = (uint32_t)t.len;
+            if (!t.next) break;
+            if (t.len < 2) return smi_fail(ctx, SMI_ERR_BAD_ARG, "fold: codeword length must be a power of two >= 2");
+            if (t.offset == 0 || t.omega == 0) return smi_fail(ctx, SMI_ERR_DIV_BY_ZERO, "no division by zero");   // src/ff.rs:182
+            uint32_t lg = 0;
+            while ((2ull << lg) < t.len) lg++;
+            SMI_TRY(ctx_scale_tables(ctx, h_inv(ctx, (uint32_t)t.offset), h_inv(ctx, (uint32_t)t.omega), lg, &tr.S));
+        }
+        return launch_fri_tail(ctx, ta);
+    }
     int emit_codeword(const uint32_t *cw, uint64_t len, uint8_t *dst) override { return launch_emit_codeword(ctx, cw, len, dst); }
     int sample_indices(const uint64_t *challenge, uint64_t size, uint64_t reduced_size, uint32_t number, uint64_t *indices,
                        uint64_t *reduced) override {
@@ -388,6 +414,12 @@ int smi_mgpu_ntt(smi_mgpu *m, uint32_t *d_strip, uint32_t *d_out, uint32_t log_n
     DeviceGuard dg__(m->ctx);
     SMI_TRY(m->dev.reset());
     return mg_ntt(m->dev, *m->coll, m->rank, m->world, d_strip, d_out, log_n, inverse, offset);
+}
+int smi_mgpu_ntt_natural(smi_mgpu *m, uint32_t *d_strip, uint32_t *d_out, uint32_t log_n, int inverse, uint64_t offset) {
+    if (!m || !d_strip || !d_out || d_strip == d_out) return SMI_ERR_BAD_ARG;
+    DeviceGuard dg__(m->ctx);
+    SMI_TRY(m->dev.reset());
+    return mg_ntt(m->dev, *m->coll, m->rank, m->world, d_strip, d_out, log_n, inverse, offset, true);
 }
 int smi_mgpu_ntt_first_digit(uint32_t log_n, uint32_t *log_r0) {
     if (!log_r0) return SMI_ERR_BAD_ARG;

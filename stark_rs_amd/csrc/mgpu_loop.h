@@ -50,6 +50,17 @@ struct MgColl {
     virtual int all_reduce_sum_u8(void *buf, size_t bytes) = 0;
 };
 
+// One round of the fused tail (MgDev::fri_tail): tree over cw (len elements) into nodes, the Fiat-Shamir round of its
+// root (MerkleRoot record at proof_slot, challenge to alpha_out unless null = last round), fold into next.
+struct MgTailRound {
+    const uint32_t *cw;
+    uint32_t *next;        // nullptr on the last round
+    uint8_t *nodes;
+    uint8_t *proof_slot;
+    uint64_t *alpha_out;   // nullptr on the last round
+    uint64_t len, offset, omega;
+};
+
 struct MgDev {
     virtual ~MgDev() {}
     virtual uint32_t prime() const = 0;
@@ -79,6 +90,23 @@ struct MgDev {
     // FRI
     virtual int fold_shard(const uint32_t *lo, const uint32_t *hi, size_t count, size_t i0, size_t full_len, const uint64_t *alpha,
                            uint64_t offset, uint64_t omega, uint32_t *out) = 0;
+    // The tail of Fri::commit (src/fri.rs:116-148) once the (replicated) codeword has at most tail_max_len() elements
+    // and at most tail_max_rounds() rounds are left: every remaining round in one call.  The product launches the
+    // single-workgroup fri_tail_kernel (csrc/hash.hip); the default is the per-round sequence, what the CPU
+    // instantiation runs.  tail_max_len() == 0: never.
+    virtual uint64_t tail_max_len() const { return 0; }
+    virtual uint32_t tail_max_rounds() const { return 0; }
+    virtual int fri_tail(const MgTailRound *rounds, uint32_t n_rounds, void *fs) {
+        for (uint32_t k = 0; k < n_rounds; k++) {
+            const MgTailRound &t = rounds[k];
+            int rc = merkle_fs(t.cw, (size_t)t.len, t.nodes, fs, t.proof_slot, t.alpha_out);
+            if (rc != SMI_OK) return rc;
+            if (!t.next) break;
+            rc = fold_shard(t.cw, t.cw + t.len / 2, (size_t)(t.len / 2), 0, (size_t)t.len, t.alpha_out, t.offset, t.omega, t.next);
+            if (rc != SMI_OK) return rc;
+        }
+        return SMI_OK;
+    }
     virtual int emit_codeword(const uint32_t *cw, uint64_t len, uint8_t *dst) = 0;
     virtual int sample_indices(const uint64_t *challenge, uint64_t size, uint64_t reduced_size, uint32_t number, uint64_t *indices,
                                uint64_t *reduced) = 0;
@@ -181,6 +209,33 @@ inline int mg_fri_run(MgDev &d, MgColl &coll, int rank, int G, const smi_fri_cfg
             cur = full;
             cur_local = length;
             sharded = false;
+        }
+        if (!sharded && length <= d.tail_max_len() && R - r <= d.tail_max_rounds()) {
+            // replicated and small: every remaining round in one call (SURVEY 8e "gather to one GPU and run the fused
+            // tail"; here every rank runs it, so nothing has to be broadcast afterwards)
+            std::vector<MgTailRound> tr((size_t)(R - r));
+            for (uint64_t k = r; k < R; k++) {
+                MgTailRound &t = tr[(size_t)(k - r)];
+                const bool last_k = k == R - 1;
+                t.cw = cur; t.len = length; t.offset = offset; t.omega = omega;
+                t.nodes = (uint8_t *)d.alloc((2 * length - 1) * 32);
+                t.proof_slot = rank == 0 ? d_proof + 33 * k : d_dummy;
+                t.alpha_out = last_k ? nullptr : d_alphas + k;
+                t.next = last_k ? nullptr : (uint32_t *)d.alloc((length / 2) * 4);
+                if (!t.nodes || (!last_k && !t.next)) return d.fail(SMI_ERR_OOM, "mgpu: tail buffers");
+                MgSide s;
+                s.cw = cur; s.nodes = t.nodes; s.top = nullptr; s.len = length; s.blk = length;
+                s.depth_local = ilog2(length); s.depth_top = 0;
+                sides.push_back(s);
+                if (last_k) break;
+                cur = t.next;
+                length /= 2;
+                omega = host_mulmod(omega, omega, p);      // src/fri.rs:146-147
+                offset = host_mulmod(offset, offset, p);
+            }
+            cur_local = length;
+            MG_TRY(d.fri_tail(tr.data(), (uint32_t)tr.size(), fs));
+            break;
         }
         uint8_t *nodes = (uint8_t *)d.alloc((2 * cur_local - 1) * 32);
         if (!nodes) return d.fail(SMI_ERR_OOM, "mgpu: tree");
@@ -336,9 +391,15 @@ inline int mg_lde_blocks(MgDev &d, MgColl &coll, int rank, int G, const uint32_t
 //   2. ONE all-to-all: rows k_0 in [h R_0/G, (h+1) R_0/G) of every strip go to rank h (each rank sends
 //      (G-1)/G of its N/G elements; point-to-point over xGMI), laid out as [R_0/G][B];
 //   3. the remaining passes, which are those of an (N/G)-point transform with first digit R_0/G;
-//   out: X[k_0 + R_0 * rest] at rest * (R_0/G) + (k_0 - rank R_0/G): natural-order runs of R_0/G outputs.
+//   out: X[k_0 + R_0 * rest] at rest * (R_0/G) + (k_0 - rank R_0/G): natural-order runs of R_0/G outputs;
+//   natural: one more all-to-all of the same volume turns those runs into this rank's contiguous natural-order block
+//        X[rank N/G .. (rank+1) N/G) -- the layout smi_mgpu_fri_* and the sharded Merkle trees consume.  (With ONE
+//        exchange the rank that owns k_0 holds every N/R_0-th output; owning a contiguous range of outputs means owning
+//        a range of `rest`, which is the other axis -- hence the second exchange: chunk d of the local result, the
+//        outputs with rest in [d B/G, (d+1) B/G), goes to rank d and lands as rows of R_0/G in rows of R_0.)
 // At G = 1 this is the direct transform, launch for launch.
-inline int mg_ntt(MgDev &d, MgColl &coll, int rank, int G, uint32_t *strip, uint32_t *out, uint32_t log_n, int inverse, uint64_t offset) {
+inline int mg_ntt(MgDev &d, MgColl &coll, int rank, int G, uint32_t *strip, uint32_t *out, uint32_t log_n, int inverse, uint64_t offset,
+                  bool natural = false) {
     using namespace mg;
     if (G < 1 || !pow2((uint64_t)G) || rank < 0 || rank >= G) return d.fail(SMI_ERR_BAD_ARG, "mgpu: world size must be a power of two");
     const uint32_t log_g = ilog2((uint64_t)G);
@@ -363,7 +424,22 @@ inline int mg_ntt(MgDev &d, MgColl &coll, int rank, int G, uint32_t *strip, uint
             MG_TRY(d.copy_rows(rowsbuf + (uint64_t)g * cols, B * 4, (g == rank ? strip : stage) + (uint64_t)g * blk, cols * 4, cols * 4, rows));
         mine = rowsbuf;
     }
-    return d.ntt_shard_rest(mine, out, log_n, log_g, inverse);
+    if (!natural || G == 1) return d.ntt_shard_rest(mine, out, log_n, log_g, inverse);
+    uint32_t *cyc = (uint32_t *)d.alloc((n / G) * 4), *stage2 = (uint32_t *)d.alloc((n / G) * 4);
+    if (!cyc || !stage2) return d.fail(SMI_ERR_OOM, "mgpu: transform buffers");
+    MG_TRY(d.ntt_shard_rest(mine, cyc, log_n, log_g, inverse));
+    const uint64_t chunk = (n / G) / G;                // = (B/G) * (R_0/G): the outputs this rank holds of one rank's block
+    std::vector<MgXfer> sends, recvs;
+    for (int peer = 0; peer < G; peer++) {
+        if (peer == rank) continue;
+        sends.push_back(MgXfer{peer, cyc + (uint64_t)peer * chunk, chunk * 4});
+        recvs.push_back(MgXfer{peer, stage2 + (uint64_t)peer * chunk, chunk * 4});
+    }
+    MG_TRY(pre(d, coll));
+    MG_TRY(coll.exchange(sends, recvs));
+    for (int h = 0; h < G; h++)      // from rank h: [rest_l][k_0 - h R_0/G]  ->  out[rest_l * R_0 + h R_0/G + ...]
+        MG_TRY(d.copy_rows(out + (uint64_t)h * rows, R0 * 4, (h == rank ? cyc : stage2) + (uint64_t)h * chunk, rows * 4, rows * 4, cols));
+    return SMI_OK;
 }
 
 struct MgStarkOut {

@@ -433,6 +433,7 @@ int dev_ntt(smi_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint32_t log_n,
         for (uint32_t c = 0; c < batch; c++) HIP_TRY(ctx, hipMemsetAsync(d_out + (size_t)c * out_stride, 0, n * 4, ctx->stream));
         return SMI_OK;
     }
+    ScaleScope pin__(ctx);   // rq.S is read by the launches below
     NttRequest rq;
     memset(&rq, 0, sizeof rq);
     rq.in = d_in; rq.out = d_out; rq.L = log_n; rq.n_in = (uint32_t)n_in; rq.batch = batch;
@@ -482,6 +483,7 @@ static int shard_request(smi_ctx *ctx, uint32_t log_n, int inverse, uint64_t off
     return SMI_OK;
 }
 int dev_ntt_shard_first(smi_ctx *ctx, uint32_t *d_strip, uint32_t log_n, uint32_t log_g, uint32_t rank, int inverse, uint64_t offset) {
+    ScaleScope pin__(ctx);
     NttRequest rq;
     SMI_TRY(shard_request(ctx, log_n, inverse, offset, &rq));
     rq.in = d_strip; rq.out = d_strip;
@@ -491,6 +493,7 @@ int dev_ntt_shard_first(smi_ctx *ctx, uint32_t *d_strip, uint32_t log_n, uint32_
     return SMI_OK;
 }
 int dev_ntt_shard_rest(smi_ctx *ctx, uint32_t *d_rows, uint32_t *d_out, uint32_t log_n, uint32_t log_g, int inverse) {
+    ScaleScope pin__(ctx);
     NttRequest rq;
     SMI_TRY(shard_request(ctx, log_n, inverse, 1, &rq));
     rq.scratch = d_rows; rq.out = d_out;

@@ -15,47 +15,12 @@
 #include <vector>
 
 #include "internal.h"
+#include "proof_parse.h"
 
 namespace {
-struct Obj {           // one ProofObject (src/stream.rs:4-9), pointing into the proof bytes
-    int tag;           // 0 MerkleRoot, 1 FieldElement, 2 FieldElements, 3 MerklePath
-    const uint8_t *p;  // payload: 32 bytes | 8 bytes | count x 8 | count x 32
-    size_t count;
-};
-uint64_t get_u64(const uint8_t *b) {
-    uint64_t v = 0;
-    for (int i = 0; i < 8; i++) v |= (uint64_t)b[i] << (8 * i);
-    return v;
-}
-// ProofStream::deserialize (src/stream.rs:66-168): an object whose header or payload is cut short is
-// dropped or shortened exactly as the reference's loops do; an unknown tag ends the stream.
-// Stops after max_objs objects; *end = the byte offset reached.
-std::vector<Obj> parse(const uint8_t *b, size_t n, size_t max_objs, size_t *end) {
-    std::vector<Obj> out;
-    size_t i = 0;
-    while (i < n && out.size() < max_objs) {
-        const uint8_t tag = b[i];
-        i++;
-        if (tag == 0) {
-            if (i + 32 <= n) { out.push_back(Obj{0, b + i, 1}); i += 32; }
-        } else if (tag == 1) {
-            if (i + 8 <= n) { out.push_back(Obj{1, b + i, 1}); i += 8; }
-        } else if (tag == 2 || tag == 3) {
-            if (i + 8 <= n) {
-                const uint64_t len = get_u64(b + i);
-                i += 8;
-                const size_t w = tag == 2 ? 8 : 32, avail = (n - i) / w, take = len < avail ? (size_t)len : avail;
-                out.push_back(Obj{tag, b + i, take});
-                i += take * w;
-            }
-        } else {
-            i--;
-            break;
-        }
-    }
-    *end = i;
-    return out;
-}
+using proofp::Obj;
+using proofp::get_u64;
+using proofp::parse;
 bool pow2(uint64_t n) { return n && !(n & (n - 1)); }
 uint32_t ilog2(uint64_t n) {
     uint32_t l = 0;

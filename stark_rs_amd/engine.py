@@ -71,13 +71,21 @@ class Engine:
         arithmetic); results are meaningless while it is on."""
         self._ck(self.L.smi_ctx_copy_probe(self.h, 1 if enable else 0))
 
+    def mix_probe(self, mixes=512):
+        """mix_state evaluations per second of the bare permutation (two hashes per lane, no memory traffic): the
+        integer-VALU ceiling the Merkle kernels are reported against."""
+        out = C.c_double()
+        self._ck(self.L.smi_ctx_mix_probe(self.h, mixes, C.byref(out)))
+        return float(out.value)
+
     def profile_read(self):
-        """-> {kernel name: {"launches", "total_ms", "alg_bytes"}} since the last read (synchronises)."""
+        """-> {kernel name: {"launches", "total_ms", "alg_bytes", "alg_mixes"}} since the last read (synchronises)."""
         arr = (_lib.KernelTime * 64)()
         n = C.c_size_t()
         self._ck(self.L.smi_ctx_profile_read(self.h, arr, 64, C.byref(n)))
         return {arr[i].name.decode(): {"launches": int(arr[i].launches), "total_ms": float(arr[i].total_ms),
-                                       "alg_bytes": float(arr[i].alg_bytes)} for i in range(n.value)}
+                                       "alg_bytes": float(arr[i].alg_bytes), "alg_mixes": float(arr[i].alg_mixes)}
+                for i in range(n.value)}
 
     @property
     def two_adicity(self):

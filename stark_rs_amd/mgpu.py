@@ -129,6 +129,7 @@ def _sig(L):
     L.smi_mgpu_lde.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, vp]
     L.smi_mgpu_stark_prove.argtypes = [vp, C.POINTER(StarkCfg), vp, vp, C.POINTER(vp), C.POINTER(sz), vp]
     L.smi_mgpu_ntt.argtypes = [vp, vp, vp, C.c_uint32, i32, C.c_uint64]
+    L.smi_mgpu_ntt_natural.argtypes = [vp, vp, vp, C.c_uint32, i32, C.c_uint64]
     L.smi_mgpu_ntt_first_digit.argtypes = [C.c_uint32, C.POINTER(C.c_uint32)]
     L._mgpu_sig = True
 
@@ -209,9 +210,11 @@ class MultiGpu:
         check(self.L.smi_mgpu_ntt_first_digit(log_n, C.byref(r0)))
         return r0.value
 
-    def ntt(self, d_strip, d_out, log_n, inverse=False, offset=1):
-        """one 2^log_n-point transform over the ranks (layouts: include/stark_mi.h, smi_mgpu_ntt)"""
-        self._ck(self.L.smi_mgpu_ntt(self.h, d_strip, d_out, log_n, 1 if inverse else 0, offset))
+    def ntt(self, d_strip, d_out, log_n, inverse=False, offset=1, natural=False):
+        """one 2^log_n-point transform over the ranks (layouts: include/stark_mi.h, smi_mgpu_ntt); natural: the result
+        as this rank's contiguous natural-order block (smi_mgpu_ntt_natural, one more all-to-all)"""
+        fn = self.L.smi_mgpu_ntt_natural if natural else self.L.smi_mgpu_ntt
+        self._ck(fn(self.h, d_strip, d_out, log_n, 1 if inverse else 0, offset))
 
     def stark_prove(self, d_trace_cols, n_cols, log_n, log_blowup, num_colinearity_tests, trace_offset=1, lde_offset=None,
                     open_columns=False):

@@ -18,7 +18,7 @@ u32p = C.POINTER(C.c_uint32)
 def emu():
     import stark_rs_amd as s
     s.build()
-    path = os.path.join(os.path.dirname(s.__file__), "build", "libstarkmi_emu.so")
+    from stark_rs_amd._lib import EMU_PATH as path
     L = C.CDLL(path)
     L.emu_ntt.argtypes = [C.c_uint64, C.c_uint64, u32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64,
                           C.c_int, C.c_uint64, C.c_uint64]

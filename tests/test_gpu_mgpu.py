@@ -193,6 +193,64 @@ def _ntt_rank_main(rank, world, port, logn, q):
     dist.destroy_process_group()
 
 
+def _ntt_commit_rank_main(rank, world, port, logn, q):
+    """smi_mgpu_ntt_natural -> smi_mgpu_fri_prove on the device: a low-degree polynomial evaluated by ONE transform over
+    the ranks, each rank's contiguous natural-order block handed to the sharded Fri::prove without a host copy."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import stark_rs_amd as s
+    from stark_rs_amd.mgpu import HipMem, HostCollectives, MultiGpu
+    from oracle import oracle as o
+    from test_mgpu_gloo import shard_strip
+    o.build()
+    eng = s.Engine(P2, G2, 0)
+    coll = HostCollectives(rank, world, HipMem())
+    mg = MultiGpu(eng, rank, world, host=coll, min_block=1 << 12)
+    n, exp, t, offset = 1 << logn, 8, 8, 5
+    coeffs = np.zeros(n, dtype=np.uint64)
+    coeffs[:n // exp] = _vals(o, 17 + logn, n // exp, P2)
+    r0 = mg.ntt_first_digit(logn)
+    d_strip = _upload(eng, shard_strip(coeffs, r0, rank, world))
+    blk = n // world
+    d_block = eng.dev_alloc(blk * 4)
+    mg.ntt(d_strip, d_block, logn, offset=offset, natural=True)
+    omega = eng.prim_nth_root(n)
+    codeword = o.fast_coset_ntt(coeffs[:n // exp], n, omega, offset, P2)
+    ok = np.array_equal(eng.dev_download(d_block, blk), codeword[rank * blk:(rank + 1) * blk])
+    proof, top = mg.fri_prove(eng.fri_cfg(omega, offset, n, exp, t), d_block, blk)
+    d_all = _upload(eng, codeword)
+    want, want_top = eng.dev_fri_prove(eng.fri_cfg(omega, offset, n, exp, t), d_all, n)      # the single-GPU proof (itself == oracle elsewhere)
+    ok = ok and proof == bytes(want) and top == list(want_top)
+    ok = ok and (rank != 0 or o.fri_verify(o.fri_cfg(omega, offset, n, exp, t, P2), proof))
+    q.put((rank, bool(ok), coll.errors))
+    mg.close()
+    eng.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,logn", [(2, 20), (4, 22)])
+def test_natural_order_transform_feeds_the_sharded_prove_on_one_gpu(oracle, world, logn):
+    import sys
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = [ctx.Process(target=_ntt_commit_rank_main, args=(r, world, port, logn, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(420)
+        assert pr.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(world))
+    assert all(g_[1] for g_ in got), got
+
+
 @pytest.mark.parametrize("world,logn", [(2, 22), (4, 24)])
 def test_sharded_ntt_ranks_on_one_gpu(oracle, world, logn):
     """smi_mgpu_ntt with 2 and 4 ranks on the box's one GPU (collectives through the gloo shim): strips in,
@@ -235,6 +293,21 @@ def _rccl_rank_main(rank, world, port, q):
     want = eng.dev_stark_prove(d, W, logn, lb, t, open_columns=True)
     roots, proof, top = mg.stark_prove(d, W, logn, lb, t, open_columns=True)
     ok = roots == [bytes(r) for r in want["column_roots"]] and proof == want["proof"] and top == want["top_indices"]
+    # the sharded extension's block and the natural-order transform's block against the single-GPU results
+    d_ref, d_blk = eng.dev_alloc(W * N * 4), eng.dev_alloc(W * (N // world) * 4)
+    eng.dev_lde(d, W, logn, lb, d_ref)
+    mg.lde(d, W, logn, lb, d_blk)
+    ref = eng.dev_download(d_ref, W * N).reshape(W, N)
+    ok = ok and np.array_equal(eng.dev_download(d_blk, W * (N // world)).reshape(W, N // world), ref[:, rank * (N // world):(rank + 1) * (N // world)])
+    from test_mgpu_gloo import shard_strip
+    L = 20
+    x = _vals(o, 3, 1 << L, P2)
+    d_x, d_y = _upload(eng, x), eng.dev_alloc(4 << L)
+    eng.dev_ntt(d_x, d_y, L, offset=7)
+    d_strip, d_nat = _upload(eng, shard_strip(x, mg.ntt_first_digit(L), rank, world)), eng.dev_alloc((4 << L) // world)
+    mg.ntt(d_strip, d_nat, L, offset=7, natural=True)
+    per = (1 << L) // world
+    ok = ok and np.array_equal(eng.dev_download(d_nat, per), eng.dev_download(d_y, 1 << L)[rank * per:(rank + 1) * per])
     q.put((rank, bool(ok)))
     mg.close()
     eng.close()
@@ -249,7 +322,9 @@ def test_rccl_over_several_gpus_when_the_box_has_them(oracle):
     if ndev < 2:
         pytest.skip("one GPU on this box: the multi-rank logic runs through the collective shim instead")
     world = 4 if ndev >= 4 else 2
+    import sys
     import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     s = socket.socket()

@@ -24,7 +24,8 @@ def _emu():
     from stark_rs_amd.mgpu import CollOps
     from stark_rs_amd._lib import FriCfg, StarkCfg
     s.build()
-    L = C.CDLL(os.path.join(os.path.dirname(s.__file__), "build", "libstarkmi_emu.so"))
+    from stark_rs_amd._lib import EMU_PATH
+    L = C.CDLL(EMU_PATH)
     sz, vp, i32 = C.c_size_t, C.c_void_p, C.c_int
     L.emu_mgpu_fri_prove.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(CollOps), i32, i32, C.POINTER(FriCfg), u32p, sz, sz, i32, vp, sz,
                                      C.POINTER(sz), vp, vp]
@@ -33,6 +34,7 @@ def _emu():
     L.emu_mgpu_lde.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(CollOps), i32, i32, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
                                C.c_uint64, u32p]
     L.emu_mgpu_ntt.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(CollOps), i32, i32, u32p, u32p, C.c_uint32, i32, C.c_uint64]
+    L.emu_mgpu_ntt_natural.argtypes = L.emu_mgpu_ntt.argtypes
     return L
 
 
@@ -153,6 +155,42 @@ def _ntt_worker(rank, world, port, logn, inverse, offset, p, g, q):
     dist.destroy_process_group()
 
 
+def _ntt_commit_worker(rank, world, port, logn, expansion, t, offset, min_block, q):
+    """smi_mgpu_ntt_natural -> smi_mgpu_fri_prove without leaving the ranks: a polynomial of degree < N / expansion
+    evaluated on offset * <w_N> by ONE transform over the ranks (zero-padded coefficients), its contiguous
+    natural-order block handed straight to the sharded Fri::prove -- block and proof against the oracle."""
+    L, coll = _init(rank, world, port)
+    from oracle import oracle as o
+    from stark_rs_amd._lib import FriCfg, lib
+    import stark_rs_amd.mgpu as m
+    n = 1 << logn
+    coeffs = np.zeros(n, dtype=np.uint32)
+    coeffs[:n // expansion] = (o.splitmix64(41 + logn, n // expansion) % np.uint64(P)).astype(np.uint32)
+    log_r0 = C.c_uint32()
+    m._sig(lib())
+    assert lib().smi_mgpu_ntt_first_digit(logn, C.byref(log_r0)) == 0
+    strip = shard_strip(coeffs, log_r0.value, rank, world).copy()
+    blk = n // world
+    block = np.zeros(blk, dtype=np.uint32)
+    rc = L.emu_mgpu_ntt_natural(P, G, C.byref(coll.ops), rank, world, strip.ctypes.data_as(u32p), block.ctypes.data_as(u32p), logn, 0, offset)
+    omega = o.ff_prim_nth_root(n)
+    codeword = o.fast_coset_ntt(coeffs[:n // expansion].astype(np.uint64), n, omega, offset)
+    ok = rc == 0 and not coll.errors and np.array_equal(block.astype(np.uint64), codeword[rank * blk:(rank + 1) * blk])
+    cfg = FriCfg(omega, offset, n, expansion, t)
+    proof = (C.c_uint8 * (1 << 22))()
+    plen = C.c_size_t()
+    top = (C.c_uint64 * (t + 1))()
+    alphas = (C.c_uint64 * 64)()
+    rc2 = L.emu_mgpu_fri_prove(P, G, C.byref(coll.ops), rank, world, C.byref(cfg), block.ctypes.data_as(u32p), blk, min_block, 1,
+                               proof, len(proof), C.byref(plen), top, alphas)
+    if ok and rc2 == 0:
+        ocfg = o.fri_cfg(omega, offset, n, expansion, t)
+        want, want_top = o.fri_prove(ocfg, codeword)
+        ok = bytes(proof[:plen.value]) == want and list(top)[:t] == want_top and (rank != 0 or o.fri_verify(ocfg, want))
+    q.put((rank, bool(ok and rc2 == 0), (rc, rc2), coll.errors))
+    dist.destroy_process_group()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -205,6 +243,17 @@ def test_native_loop_sharded_ntt_on_the_pass_pipeline(oracle, world, logn, inver
     """smi_mgpu_ntt's loop: pass 0 on column strips, ONE all-to-all, the remaining passes -- equals the
     single transform (Polynomial::eval_domain / interpolate_domain on a geometric domain)."""
     _run(_ntt_worker, world, (logn, inverse, offset, p, g))
+
+
+@pytest.mark.parametrize("world,logn,expansion,t,offset,min_block", [
+    (2, 16, 8, 8, 3, 1 << 10),
+    (4, 16, 4, 4, 7, 1 << 9),
+    (8, 17, 8, 8, 5, 1 << 9),        # BASELINE configs[3]'s world size
+])
+def test_native_loop_natural_order_transform_feeds_the_sharded_commit(oracle, world, logn, expansion, t, offset, min_block):
+    """VERDICT r02 "weak" 8: the sharded transform's block-cyclic runs could not feed smi_mgpu_fri_*; the natural-order
+    mode (one more all-to-all) hands each rank its contiguous block, and evaluation -> commit -> prove stays on the ranks."""
+    _run(_ntt_commit_worker, world, (logn, expansion, t, offset, min_block))
 
 
 def test_native_loop_statuses_mirror_the_reference_asserts(oracle):
