@@ -208,8 +208,11 @@ def hash_roofline(kernels, ceiling_mix_per_s, stage_ms, n_leaves, n_trees, pmc_n
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # Defaults: a timed region of more than a second.  A 20-step region (15 ms) is over before the chip has settled --
+    # measured r03: 0.783 ms per step over 20 steps after 3 warm-ups, 0.697 ms over 1 500 back-to-back steps -- so the
+    # headline is the sustained figure and the short burst is reported beside it (`burst`).
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-extras", action="store_true", help="skip prove / 2^20 / four-step / cpu legs")
     ap.add_argument("--in-loop-only", action="store_true",
                     help="roofline leg: skip the pass that brackets every launch and the copy-only twins, so that a profiler "
@@ -283,6 +286,18 @@ def main():
     def step():
         eng.dev_lde(trace.data_ptr(), N_COLS, LOG_ROWS, LOG_BLOWUP, out.data_ptr())
 
+    # burst: what rounds 1 and 2 reported as the headline -- 20 steps after 3 warm-up steps on a GPU that was idle until
+    # then (clocks still ramping); kept for continuity, never the headline
+    burst = None
+    if not args.in_loop_only:
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        burst = {"steps": 20, "warmup": 3, "ms_per_step": 1e3 * (time.perf_counter() - tb) / 20, "note": "rank-local, from an idle GPU"}
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -299,10 +314,10 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    # sustained: at least a second of back-to-back steps (the 20-step headline is ~15 ms, too short to say anything
-    # about the clocks the chip holds under its power limit): same loop, same brackets, reported beside the headline
+    # sustained: when the caller asked for a short region (--steps below ~1 s of work), also time at least a second of
+    # back-to-back steps, the same way, and report it beside the headline
     sustained = None
-    if not args.in_loop_only:
+    if not args.in_loop_only and elapsed < 0.9:
         n_sus = max(200, int(1.2 / max(elapsed / args.steps, 1e-6)))
         barrier()
         torch.cuda.synchronize()
@@ -420,6 +435,8 @@ def main():
     }
     if sustained is not None:
         result["sustained"] = sustained
+    if burst is not None:
+        result["burst"] = burst
 
     # The headline line must survive anything the extra legs do: a watchdog thread prints what has
     # been measured so far and exits NON-ZERO if an extra (e.g. a collective on a flaky peer) hangs;

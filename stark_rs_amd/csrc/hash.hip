@@ -392,8 +392,9 @@ __global__ __launch_bounds__(SMI_HASH_THREADS) void mix_probe_kernel(uint32_t *o
     hashc::State2 st;
 #pragma unroll
     for (int w = 0; w < 32; w++) st.s[w] = (threadIdx.x * 2654435761u + (uint32_t)w * 40503u + blockIdx.x) & 0x00FF00FFu;
+    const hashc::MixK K = hashc::mix_consts();
 #pragma unroll 1
-    for (uint32_t i = 0; i < mixes; i++) hashc::mix2_t<true>(st);
+    for (uint32_t i = 0; i < mixes; i++) hashc::mix2_t<true>(st, K);
     uint32_t x = 0;
 #pragma unroll
     for (int w = 0; w < 32; w++) x ^= st.s[w];

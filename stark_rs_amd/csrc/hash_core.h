@@ -63,30 +63,26 @@ SMI_HD uint32_t pk_mad_u16(uint32_t a, uint32_t m, uint32_t c) {
 #endif
 }
 
-// (mask & a) | (~mask & b) and a ^ b ^ c as single VALU ops (the compiler otherwise splits them).
-SMI_HD uint32_t bfi32(uint32_t mask, uint32_t a, uint32_t b) {
+// Three-input bit operations as single VALU ops (gfx950 v_bitop3_b32; result bit = TT[(a << 2) | (b << 1) | c]).
+// Through the compiler's builtin rather than inline asm: the optimizer folds them on constants, schedules them
+// like any other VALU op and needs no hazard s_nop after them (an asm result read by the next instruction costs
+// one: 130 of them per thread in merkle_sub_kernel, r03).  It issues at twice the rate of v_bfi_b32 / v_xor3
+// (tools/ubench_valu.hip).
+template <int TT> SMI_HD uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t r;
-    // as a three-input bit op (table 0xCA = (m & a) | (~m & b)): v_bitop3_b32 issues at twice the
-    // rate of v_bfi_b32 on gfx950 (tools/ubench_valu.hip)
-    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xca" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
-    return r;
+    return __builtin_amdgcn_bitop3_b32(a, b, c, TT);
 #else
-    return (mask & a) | (~mask & b);
+    uint32_t r = 0;
+    for (int i = 0; i < 8; i++)
+        if ((TT >> i) & 1) r |= ((i & 4) ? a : ~a) & ((i & 2) ? b : ~b) & ((i & 1) ? c : ~c);
+    return r;
 #endif
 }
-SMI_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t r;  // gfx950 three-input bit op; 0x96 is the (operand-order independent) parity table
-    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-#else
-    return a ^ b ^ c;
-#endif
-}
-// The inline-asm forms above are opaque to the optimizer.  Where every input of an S-box tail or of a
-// linear-mix XOR is a compile-time constant (the half of a leaf's state the 8-byte message never
-// reaches, in its first mix) these wrappers take the plain C expression instead, which folds away.
+SMI_HD uint32_t bfi32(uint32_t mask, uint32_t a, uint32_t b) { return bitop3<0xCA>(mask, a, b); }   // (mask & a) | (~mask & b)
+SMI_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return bitop3<0x96>(a, b, c); }
+// Where every input of an S-box tail or of a linear-mix XOR is a compile-time constant (the half of a leaf's
+// state the 8-byte message never reaches, in its first mix) these wrappers take the plain C expression, which
+// folds away (a leftover of the inline-asm forms; harmless with the builtin).
 #if defined(__HIP_DEVICE_COMPILE__)
 #define SMI_CONST_P(x) __builtin_constant_p(x)
 #else
@@ -149,6 +145,16 @@ SMI_HD uint32_t perm8(uint32_t hi, uint32_t lo, uint32_t sel) {
 #endif
 }
 
+// The VGPR-held constants of a mix (masks, the deferred ^0x63, the S-box multiplier): made ONCE per hash by the
+// caller and passed down, so that the closing-mix loops do not re-materialise them every iteration (the empty asm
+// of vreg() is re-executed wherever its call is inlined: 4 v_mov per mix2 inside the loops before, r03).
+struct MixK {
+    uint32_t kFE, kFF, k63, k502, kHI;
+};
+SMI_HD MixK mix_consts() {
+    return MixK{vreg(0x00FE00FEu), vreg(0x00FF00FFu), vreg(0x00630063u), vreg(0x01F601F6u), vreg(0xFFFF0000u)};
+}
+
 // State convention: the TRUE state byte is (stored lane + pending round constant) mod 256, where
 // the round constants of the previous mix (src/hash.rs:83-85) may still be pending; only the low 8
 // bits of a lane are meaningful (bits 8..15 may hold carry dirt below 2^16).
@@ -171,16 +177,16 @@ SMI_HD void flush(State &st) {
 
 // src/hash.rs:59-86.  PENDING: the previous mix's round constants have not been added yet (they
 // are folded into this S-box's multiply-add).  Leaves its own round constants pending.
-template <bool PENDING> SMI_HD void mix_t(State &st) {
+template <bool PENDING> SMI_HD void mix_t(State &st, const MixK &K) {
     constexpr Consts C = make_consts();
     uint32_t *s = st.s;
     // (1) S-box  rotl1(251*b) (^0x63 deferred): t = 502*(b + rc); result = (t & 0xFE) | bit 8 of t.
     // Bits 8..15 of the result lanes are left dirty; the linear layer's last XOR masks them.
-    const uint32_t kFE = vreg(0x00FE00FEu), kFF = vreg(0x00FF00FFu), k63 = vreg(0x00630063u), kHI = vreg(0xFFFF0000u);
+    const uint32_t kFE = K.kFE, kFF = K.kFF, k63 = K.k63, kHI = K.kHI, k502 = K.k502;   // k502: see mix2_t
     uint32_t r[16];
 #pragma unroll
     for (int w = 0; w < 16; w++) {
-        const uint32_t t = pk_mad_u16(s[w], 0x01F601F6u, PENDING ? C.rc502[w] : 0u);
+        const uint32_t t = pk_mad_u16(s[w], SMI_CONST_P(s[w]) ? 0x01F601F6u : k502, PENDING ? C.rc502[w] : 0u);
         r[w] = sbox_tail(t, kFE);
     }
     // (2) linear mix: new = (t0^t1^t2^t3) ^ {t2, t1, t3, t0}, with the deferred ^0x63 (it passes
@@ -216,11 +222,13 @@ template <bool PENDING> SMI_HD void mix_t(State &st) {
     for (int w = 0; w < 16; w++) s[w] = N[w];
 }
 
+template <bool PENDING> SMI_HD void mix_t(State &st) { mix_t<PENDING>(st, mix_consts()); }
 // One complete mix_state on a fully applied state (used by the single-lane transcript kernels).
-SMI_HD void mix(State &st) {
-    mix_t<false>(st);
+SMI_HD void mix(State &st, const MixK &K) {
+    mix_t<false>(st, K);
     flush(st);
 }
+SMI_HD void mix(State &st) { mix(st, mix_consts()); }
 
 // byte accessors in the paired-lane layout
 SMI_HD uint32_t get_byte(const State &st, int i) { return (st.s[i & 15] >> ((i & 16) ? 16 : 0)) & 0xFFu; }
@@ -267,6 +275,13 @@ SMI_HD uint32_t add_bytes(uint32_t a, uint32_t b) {   // four independent sums m
     const uint32_t k7F = vreg(0x7F7F7F7Fu), k80 = vreg(0x80808080u);
     return ((a & k7F) + (b & k7F)) ^ ((a ^ b) & k80);
 }
+// (a ^ f) + m per byte: the XOR of the absorb recurrence folded into the two halves of the byte add
+// (5 ops instead of 1 + 5): low seven bits (a ^ f) & 7F + m & 7F, top bits (a ^ f ^ m) & 80
+SMI_HD uint32_t xor_add_bytes(uint32_t a, uint32_t f, uint32_t m) {
+    const uint32_t k7F = vreg(0x7F7F7F7Fu), k80 = vreg(0x80808080u);
+    const uint32_t t = bitop3<0x28>(a, f, k7F) + (m & k7F);      // 0x28: (a ^ b) & c
+    return bitop3<0x78>(t, xor3(a, f, m), k80);                   // 0x78: a ^ (b & c)
+}
 SMI_HD uint32_t rotl3_bytes(uint32_t x) { return bfi32(vreg(0xF8F8F8F8u), x << 3, x >> 5); }
 
 // src/hash.rs:15-20 for one full chunk.  With v_i the value byte i takes when it is processed,
@@ -278,10 +293,8 @@ SMI_HD void absorb32_words(uint32_t P[8], const uint32_t M[8]) {
     uint32_t V[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        uint32_t x = P[j];
-        if (j == 1) x ^= V[0] << 24;
-        if (j >= 2) x ^= funnel(V[j - 1], V[j - 2], 8);   // v_{4j-7} .. v_{4j-4}
-        V[j] = rotl3_bytes(add_bytes(x, M[j]));
+        if (j == 0) V[j] = rotl3_bytes(add_bytes(P[j], M[j]));
+        else V[j] = rotl3_bytes(xor_add_bytes(P[j], j == 1 ? V[0] << 24 : funnel(V[j - 1], V[j - 2], 8), M[j]));   // ^ v_{4j-7} .. v_{4j-4}
     }
     V[0] ^= funnel(V[7], V[6], 8);   // bytes 0..3 ^= v_25..v_28
     V[1] ^= V[7] >> 8;               // bytes 4..6 ^= v_29..v_31
@@ -370,9 +383,10 @@ SMI_HD void leaf_hash(uint32_t v, uint32_t d[8]) {
     leaf_absorb_words(v, P);
     State st;
     from_words(P, st);
-    mix_t<false>(st);
+    const MixK K = mix_consts();
+    mix_t<false>(st, K);
 #pragma unroll 1
-    for (int k = 0; k < 8; k++) mix_t<true>(st);
+    for (int k = 0; k < 8; k++) mix_t<true>(st, K);
     flush(st);
     to_words(st, d);
 }
@@ -389,13 +403,14 @@ template <int UNROLL = 1> SMI_HD void node_hash(const uint32_t l[8], const uint3
     absorb32_words(P, l);
     State st;
     from_words(P, st);
-    mix(st);
+    const MixK K = mix_consts();
+    mix(st, K);
     to_words(st, P);
     absorb32_words(P, r);
     from_words(P, st);
-    mix_t<false>(st);
+    mix_t<false>(st, K);
 #pragma unroll UNROLL
-    for (int k = 0; k < 8; k++) mix_t<true>(st);
+    for (int k = 0; k < 8; k++) mix_t<true>(st, K);
     flush(st);
     to_words(st, d);
 }
@@ -426,14 +441,18 @@ SMI_HD void flush2(State2 &st) {
 #pragma unroll
     for (int w = 0; w < 32; w++) st.s[w] += C.rc[w];
 }
-template <bool PENDING> SMI_HD void mix2_t(State2 &st) {
+template <bool PENDING> SMI_HD void mix2_t(State2 &st, const MixK &K) {
     constexpr Consts2 C = make_consts2();
     uint32_t *s = st.s;
-    const uint32_t kFE = vreg(0x00FE00FEu), kFF = vreg(0x00FF00FFu), k63 = vreg(0x00630063u);
+    const uint32_t kFE = K.kFE, kFF = K.kFF, k63 = K.k63;
+    // A VOP3P instruction takes ONE scalar/literal source: with the multiplier in a VGPR the 32 different round-constant
+    // addends can be that one (SGPRs, s_mov on the scalar unit) instead of being re-materialised into VGPRs by
+    // v_mov inside the mix loop (10 per mix2 before, r03).
+    const uint32_t k502 = K.k502;
     uint32_t r[32];
 #pragma unroll
     for (int w = 0; w < 32; w++) {
-        const uint32_t t = pk_mad_u16(s[w], 0x01F601F6u, PENDING ? C.rc502[w] : 0u);
+        const uint32_t t = pk_mad_u16(s[w], SMI_CONST_P(s[w]) ? 0x01F601F6u : k502, PENDING ? C.rc502[w] : 0u);
         r[w] = sbox_tail(t, kFE);
     }
 #pragma unroll
@@ -454,8 +473,9 @@ template <bool PENDING> SMI_HD void mix2_t(State2 &st) {
 #pragma unroll
     for (int w = 0; w < 32; w++) s[w] = N[w];
 }
-SMI_HD void mix2(State2 &st) {
-    mix2_t<false>(st);
+template <bool PENDING> SMI_HD void mix2_t(State2 &st) { mix2_t<PENDING>(st, mix_consts()); }
+SMI_HD void mix2(State2 &st, const MixK &K) {
+    mix2_t<false>(st, K);
     flush2(st);
 }
 SMI_HD void from_words2(const uint32_t X[8], const uint32_t Y[8], State2 &st) {
@@ -471,9 +491,12 @@ SMI_HD void from_words2(const uint32_t X[8], const uint32_t Y[8], State2 &st) {
 SMI_HD void to_words2(const State2 &st, uint32_t X[8], uint32_t Y[8]) {
 #pragma unroll
     for (int j = 0; j < 8; j++) {
+        // two perms gather (X_4j, X_4j+1 | Y_4j, Y_4j+1) and (X_4j+2, X_4j+3 | Y_4j+2, Y_4j+3), two more split them
+        // into the X word and the Y word: 4 ops per pair of words instead of 6
         const uint32_t *q = st.s + 4 * j;
-        X[j] = perm8(q[1], q[0], 0x0C0C0400u) | perm8(q[3], q[2], 0x04000C0Cu);
-        Y[j] = perm8(q[1], q[0], 0x0C0C0602u) | perm8(q[3], q[2], 0x06020C0Cu);
+        const uint32_t a = perm8(q[1], q[0], 0x06020400u), b = perm8(q[3], q[2], 0x06020400u);
+        X[j] = perm8(b, a, 0x05040100u);
+        Y[j] = perm8(b, a, 0x07060302u);
     }
 }
 // two leaves / two nodes at once: the same digests as leaf_hash / node_hash on each
@@ -483,9 +506,10 @@ SMI_HD void leaf_hash2(uint32_t v0, uint32_t v1, uint32_t d0[8], uint32_t d1[8])
     leaf_absorb_words(v1, Y);
     State2 st;
     from_words2(X, Y, st);
-    mix2_t<false>(st);
+    const MixK K = mix_consts();
+    mix2_t<false>(st, K);
 #pragma unroll 1
-    for (int k = 0; k < 8; k++) mix2_t<true>(st);
+    for (int k = 0; k < 8; k++) mix2_t<true>(st, K);
     flush2(st);
     to_words2(st, d0, d1);
 }
@@ -499,14 +523,15 @@ SMI_HD void node_hash2(const uint32_t l0[8], const uint32_t r0[8], const uint32_
     absorb32_words(Y, l1);
     State2 st;
     from_words2(X, Y, st);
-    mix2(st);
+    const MixK K = mix_consts();
+    mix2(st, K);
     to_words2(st, X, Y);
     absorb32_words(X, r0);
     absorb32_words(Y, r1);
     from_words2(X, Y, st);
-    mix2_t<false>(st);
+    mix2_t<false>(st, K);
 #pragma unroll 1
-    for (int k = 0; k < 8; k++) mix2_t<true>(st);
+    for (int k = 0; k < 8; k++) mix2_t<true>(st, K);
     flush2(st);
     to_words2(st, d0, d1);
 }
@@ -558,9 +583,10 @@ SMI_HD void row_hash2(const uint32_t *v0, const uint32_t *v1, int W, uint32_t d0
     row_chunk_words(v1, W, Y);
     State2 st;
     from_words2(X, Y, st);
-    mix2_t<false>(st);
+    const MixK K = mix_consts();
+    mix2_t<false>(st, K);
 #pragma unroll 1
-    for (int k = 0; k < 8; k++) mix2_t<true>(st);
+    for (int k = 0; k < 8; k++) mix2_t<true>(st, K);
     flush2(st);
     to_words2(st, d0, d1);
 }

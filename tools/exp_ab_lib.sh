@@ -3,7 +3,7 @@
 # (SMI_LIB), three alternating rounds of the headline step.   bash tools/exp_ab_lib.sh [tag]
 set -e
 T=${1:-p}
-B="python3 bench.py --no-extras --steps 20 --warmup 3"
+B="python3 bench.py --no-extras --steps 1000 --warmup 200"
 show() { python3 -c "
 import json,sys
 r=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); k=r['roofline']['kernels']

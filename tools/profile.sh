@@ -9,8 +9,8 @@ TAG=${1:-run}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 bench.py --no-extras --in-loop-only --steps 20 --warmup 3"
-BENCH2="python3 bench.py --no-extras --in-loop-only --steps 10 --warmup 3"
+BENCH="python3 bench.py --no-extras --in-loop-only --steps 200 --warmup 50"
+BENCH2="python3 bench.py --no-extras --in-loop-only --steps 100 --warmup 50"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o lde -- $BENCH > $OUT/bench_stats.json 2> $OUT/stats.err
 echo "stats done"
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/fetch -o lde -- $BENCH > /dev/null 2> $OUT/fetch.err
