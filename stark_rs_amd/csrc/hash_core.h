@@ -104,6 +104,15 @@ SMI_HD uint32_t lin_out(uint32_t T, uint32_t t, uint32_t kFF) {   // (T ^ t), la
 // v_add3_u32 costs what two v_add_u32 cost (4 cycles per wave either way), so the choice is left
 // to the compiler: it keeps s[w] + s[w+1] off the dependent chain of the ring add.
 SMI_HD uint32_t add3(uint32_t a, uint32_t b, uint32_t c) { return a + (b + c); }
+// a + b that stays an add of its own (the empty asm hides it from the pattern that forms v_add3_u32); used by
+// tools/ubench_mix.hip's two-add variant of the ring add (measured and not adopted, see mix2_t)
+SMI_HD uint32_t pair_sum(uint32_t a, uint32_t b) {
+    uint32_t r = a + b;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(r));
+#endif
+    return r;
+}
 
 // The high 16-bit lane copied into both lanes (v_perm_b32), and {hi:lo} >> 16 (v_alignbit_b32).
 SMI_HD uint32_t dup_hi16(uint32_t a) {
@@ -464,7 +473,11 @@ template <bool PENDING> SMI_HD void mix2_t(State2 &st, const MixK &K) {
         s[4 * q + 2] = lin_out(T, t3, kFF);
         s[4 * q + 3] = lin_out(T, t0, kFF);
     }
-    // src/hash.rs:77-81 as written, both lanes at once; a lane never exceeds 32*2*255 + 1020 < 2^16
+    // src/hash.rs:77-81 as written, both lanes at once; a lane never exceeds 32*2*255 + 1020 < 2^16.
+    // One v_add3_u32 per word.  Measured r03 (profiles/r03_d_ringadd_ab.log): spelling it as two plain adds -- the pair
+    // sums off the chain, one full-rate add per word on it (pair_sum) -- wins 7 % in a bare mix loop at 4 waves per SIMD
+    // (tools/ubench_mix.hip) and LOSES 6 % in the Merkle kernels, which run 8 waves per SIMD at 62 VGPRs: there the
+    // chain's latency is hidden already and the 32 extra instructions per mix are pure issue cost (prove 11.93 -> 12.66 ms).
     uint32_t N[32];
     N[0] = add3(s[0], s[1], s[31]);
 #pragma unroll
