@@ -334,8 +334,12 @@ int smi_stark_verify(smi_ctx *ctx, const smi_stark_cfg *cfg, const uint8_t *colu
  * smi_dev_stark_prove over the G ranks.  Every rank makes the same calls in the same order; the
  * collectives (all-gather of the G sub-roots per tree, one grouped send/recv per fold and for the
  * extension's all-to-all, one byte-sum all-reduce of the proof) run inside the library on the
- * context's stream.  Results are bit-identical to the single-GPU entry points.  World sizes are
- * powers of two. */
+ * context's stream.  Results are bit-identical to the single-GPU entry points by construction and
+ * as far as they have been run: at every world size (2, 4, 8) on the CPU instantiation of the same loop,
+ * with 2 and 4 ranks on one GPU through smi_mgpu_create_with (host-staged collectives), and over a real
+ * RCCL communicator at world size 1.  An RCCL communicator with MORE THAN ONE RANK has not been exercised:
+ * the development boxes have one GPU.  bench.py therefore self-checks three entry points against their
+ * single-GPU twins on every rank before it times anything on several GPUs.  World sizes are powers of two. */
 typedef struct smi_mgpu smi_mgpu;
 #define SMI_MGPU_ID_BYTES 128
 /* rank 0: ncclGetUniqueId; the caller carries the 128 bytes to the other ranks (any channel) */
