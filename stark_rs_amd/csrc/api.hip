@@ -122,6 +122,7 @@ void smi_ctx_destroy(smi_ctx *ctx) {
         if (ctx->pin[i]) (void)hipHostFree(ctx->pin[i]);
         if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]);
     }
+    if (ctx->pin_out) (void)hipHostFree(ctx->pin_out);
     (void)hipFree(ctx->d_flag);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -197,6 +198,22 @@ int smi_ctx_profile_read(smi_ctx *ctx, smi_kernel_time *out, size_t cap, size_t 
 uint64_t smi_ctx_modulus(const smi_ctx *ctx) { return ctx ? ctx->fs.F.p : 0; }
 uint32_t smi_ctx_two_adicity(const smi_ctx *ctx) { return ctx ? ctx->fs.K : 0; }
 
+int ctx_pin_out(smi_ctx *ctx, size_t bytes, uint8_t **out) {
+    if (bytes > ctx->pin_out_bytes) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // a copy into the old buffer may still be in flight
+        if (ctx->pin_out) (void)hipHostFree(ctx->pin_out);
+        ctx->pin_out = nullptr;
+        ctx->pin_out_bytes = 0;
+        const size_t want = bytes < ((size_t)2 << 20) ? ((size_t)2 << 20) : bytes + bytes / 4;
+        if (hipHostMalloc(&ctx->pin_out, want, hipHostMallocDefault) != hipSuccess) {
+            ctx->pin_out = nullptr;
+            return smi_fail(ctx, SMI_ERR_OOM, "hipHostMalloc (result buffer)");
+        }
+        ctx->pin_out_bytes = want;
+    }
+    *out = (uint8_t *)ctx->pin_out;
+    return SMI_OK;
+}
 int ctx_tmp(smi_ctx *ctx, int slot, size_t bytes, void **out) {
     if (bytes > ctx->tmp_bytes[slot]) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -530,15 +530,28 @@ int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, si
     }
     if (hipGetLastError() != hipSuccess) return bail(smi_fail(ctx, SMI_ERR_HIP, "fri kernel launch"));
 
-    // one synchronising copy-back
-    std::vector<uint8_t> proof(proof_len);
-    if (hipMemcpyAsync(proof.data(), run->d_proof, proof_len, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+    // one synchronising copy-back, through the context's pinned landing buffer: proof | challenges | indices
+    const size_t off_al = (proof_len + 7) & ~(size_t)7, off_top = off_al + 8 * R, off_ride = off_top + 8 * (t + 1);
+    const void *ride_src = ctx->ride_src;
+    const size_t ride_bytes = ride_src ? ctx->ride_bytes : 0;
+    void *ride_dst = ctx->ride_dst;
+    ctx->ride_src = nullptr;
+    ctx->ride_bytes = 0;
+    ctx->ride_dst = nullptr;
+    uint8_t *land = nullptr;
+    if ((rc = ctx_pin_out(ctx, off_ride + ride_bytes, &land)) != SMI_OK) return bail(rc);
+    if (ride_bytes) (void)hipMemcpyAsync(land + off_ride, ride_src, ride_bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (hipMemcpyAsync(land, run->d_proof, proof_len, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
         return bail(smi_fail(ctx, SMI_ERR_HIP, "copy proof"));
-    std::vector<uint64_t> alphas(R), top(t + 1);
-    (void)hipMemcpyAsync(alphas.data(), d_alphas, 8 * (R - 1), hipMemcpyDeviceToHost, ctx->stream);
-    if (do_query) (void)hipMemcpyAsync(top.data(), d_top, 8 * t, hipMemcpyDeviceToHost, ctx->stream);
+    if (R > 1) (void)hipMemcpyAsync(land + off_al, d_alphas, 8 * (R - 1), hipMemcpyDeviceToHost, ctx->stream);
+    if (do_query && t) (void)hipMemcpyAsync(land + off_top, d_top, 8 * t, hipMemcpyDeviceToHost, ctx->stream);
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return bail(smi_hip_fail(ctx, e, "fri sync"));
+    std::vector<uint8_t> proof(land, land + proof_len);
+    std::vector<uint64_t> alphas(R), top(t + 1);
+    if (R > 1) memcpy(alphas.data(), land + off_al, 8 * (R - 1));
+    if (do_query && t) memcpy(top.data(), land + off_top, 8 * t);
+    if (ride_bytes && ride_dst) memcpy(ride_dst, land + off_ride, ride_bytes);
 
     if (roots_host)
         for (uint64_t r = 0; r < R; r++) memcpy(roots_host + 32 * r, proof.data() + 33 * r + 1, 32);

@@ -42,6 +42,13 @@ struct smi_ctx {
     int *d_flag = nullptr;         // non-canonical input flag
     void *pin[2] = {nullptr, nullptr};          // pinned chunks of the large host <-> device transfers
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    void *pin_out = nullptr;       // pinned landing buffer of a prove's results (proof bytes, challenges, indices, roots)
+    size_t pin_out_bytes = 0;
+    // a small device buffer that rides back with the next fri_run's single copy-back (the column roots of
+    // smi_dev_stark_prove): set by the caller, consumed and cleared by fri_run
+    const void *ride_src = nullptr;
+    size_t ride_bytes = 0;
+    void *ride_dst = nullptr;
     std::string err;
     bool prof_on = false;
     char prof_only[56] = {0};   // smi_ctx_profile_only: bracket only launches whose name contains this (empty: all)
@@ -123,6 +130,10 @@ int smi_fail(smi_ctx *ctx, int code, const char *msg);
 // grows (never shrinks) a context-owned staging buffer
 int ctx_tmp(smi_ctx *ctx, int slot, size_t bytes, void **out);
 int ctx_scratch(smi_ctx *ctx, size_t elems, uint32_t **out);
+// Pinned host memory for the results a prove copies back (grows, never shrinks): a device-to-host copy into pageable
+// memory is staged and blocks per call (r03 trace: 6 copies, 105 us of idle at the end of a prove); into pinned
+// memory the copies queue behind the last kernel and one synchronisation waits for all of them.
+int ctx_pin_out(smi_ctx *ctx, size_t bytes, uint8_t **out);
 NttTables ctx_tables(const smi_ctx *ctx, int inverse);
 // device tables of c * q^i, i < 2^L (cached per (c,q,L))
 // device table of w_m^e, e < m = 2^log_m (forward root), as Tw2 pairs; cached per log_m (log_m <= 17)

@@ -130,7 +130,15 @@ __global__ __launch_bounds__(1 << (LOGR + LOGW - 4)) void ntt_copy_probe_kernel(
     const uint32_t tid = threadIdx.x, batch = blockIdx.y;
     const typename NP::TileId t = NP::tile_id(a, blockIdx.x);
     uint32_t v[NP::V];
-    if constexpr (KIND == PASS_LAST) {
+    // Layout experiment (SMI_PROBE_LINEAR, development only): what the pass would cost if its tile were one contiguous run
+    // in the inter-pass buffer -- bit 0: loads linear, bit 1: stores linear (the other side keeps the pass's own pattern)
+    const uint32_t lin = a.flags >> 30;
+    const uint64_t lin_in = (uint64_t)batch * a.in_stride + (uint64_t)blockIdx.x * NP::TILE;
+    const uint64_t lin_out = (uint64_t)batch * a.out_stride + (uint64_t)blockIdx.x * NP::TILE;
+    if ((lin & 1u) && KIND != PASS_FIRST) {
+#pragma unroll
+        for (int i = 0; i < NP::V; i++) v[i] = ld32(a.in + lin_in, (uint32_t)i * NP::NT + tid);
+    } else if constexpr (KIND == PASS_LAST) {
         if (a.flags & NTT_LAST_DIRECT) NP::load_rows_direct(a, t, batch, v, tid);
         else NP::load_rows(a, t, batch, v, tid);
     } else if constexpr (KIND == PASS_MID) {
@@ -142,6 +150,11 @@ __global__ __launch_bounds__(1 << (LOGR + LOGW - 4)) void ntt_copy_probe_kernel(
         case 4: NP::template load_regs<4>(a, t, batch, v, tid); break;
         default: NP::template load_regs<0>(a, t, batch, v, tid); break;
         }
+    }
+    if ((lin & 2u) && KIND != PASS_LAST) {
+#pragma unroll
+        for (int i = 0; i < NP::V; i++) st32(a.out + lin_out, (uint32_t)i * NP::NT + tid, v[i] + 1u);
+        return;
     }
     uint32_t *out = a.out + (uint64_t)batch * a.out_stride + t.out_base;
     const uint32_t sh = KIND == PASS_LAST ? a.Sp : a.L - a.Sp - LOGR;   // stride of the frequency index in the output
@@ -299,7 +312,10 @@ struct HipLauncher {
         }
         ntt_pass_kernel<LR, LW, KIND, CAP><<<dim3(a.n_tiles, a.batch), 1 << (LR + LW - 4), 0, ctx->stream>>>(a);
     }
-    template <int LR, int LW> void launch_probe(int kind, const PassArgs &a) {
+    template <int LR, int LW> void launch_probe(int kind, const PassArgs &a0) {
+        static const uint32_t lin = getenv("SMI_PROBE_LINEAR") ? (uint32_t)atoi(getenv("SMI_PROBE_LINEAR")) & 3u : 0u;
+        PassArgs a = a0;
+        a.flags |= lin << 30;      // the two top bits of flags are free (ntt_core.h)
         const dim3 grid(a.n_tiles, a.batch);
         if (kind == PASS_FIRST) ntt_copy_probe_kernel<LR, LW, PASS_FIRST><<<grid, 1 << (LR + LW - 4), 0, ctx->stream>>>(a);
         else if (kind == PASS_MID) ntt_copy_probe_kernel<LR, LW, PASS_MID><<<grid, 1 << (LR + LW - 4), 0, ctx->stream>>>(a);

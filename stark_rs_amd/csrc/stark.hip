@@ -171,7 +171,16 @@ int smi_dev_stark_prove(smi_ctx *ctx, const smi_stark_cfg *cfg, const uint32_t *
     // the column openings need the top-level indices whether or not the caller wants them back
     std::vector<uint64_t> top_tmp(top_indices ? 0 : (size_t)cfg->num_colinearity_tests);
     if (!top_indices && !top_tmp.empty()) top_indices = top_tmp.data();
-    SMI_TRY(fri_run(ctx, &fc, d_cw, N, true, false, nullptr, &bytes, top_indices, nullptr, nullptr, nullptr, nullptr));
+    if (column_roots) {   // the roots come back with fri_run's one copy-back instead of a copy and a sync of their own
+        ctx->ride_src = d_roots;
+        ctx->ride_bytes = 32 * (size_t)T;
+        ctx->ride_dst = column_roots;
+    }
+    const int fri_rc = fri_run(ctx, &fc, d_cw, N, true, false, nullptr, &bytes, top_indices, nullptr, nullptr, nullptr, nullptr);
+    ctx->ride_src = nullptr;   // not consumed if fri_run failed early
+    ctx->ride_bytes = 0;
+    ctx->ride_dst = nullptr;
+    SMI_TRY(fri_rc);
     mark(4);
     if (cfg->open_columns && !cfg->row_leaves && cfg->num_colinearity_tests) {
         // the top-level indices are on the host now (fri_run synchronised): one more small launch
@@ -193,10 +202,6 @@ int smi_dev_stark_prove(smi_ctx *ctx, const smi_stark_cfg *cfg, const uint32_t *
         const size_t at = bytes.size();
         bytes.resize(at + ob);
         HIP_TRY(ctx, hipMemcpyAsync(bytes.data() + at, d_open, ob, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    if (column_roots) {   // fri_run has synchronised; the arena (and d_roots) is intact until the next reset
-        HIP_TRY(ctx, hipMemcpyAsync(column_roots, d_roots, 32 * (size_t)T, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     if (timed) {
