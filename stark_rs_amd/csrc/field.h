@@ -89,6 +89,14 @@ SMI_HD uint32_t mont_mul_c(uint32_t a, uint32_t b, uint32_t bq, const Fp &F) {
 SMI_HD uint32_t to_mont(uint32_t a, const Fp &F) { return mont_mul(a, F.r2, F); }
 SMI_HD uint32_t from_mont(uint32_t a, const Fp &F) { return mont_mul(a, 1u, F); }
 
+// Montgomery form of an arbitrary u64 reduced mod p (an unreduced Fiat-Shamir challenge, src/fiat_shamir.rs:23-24) without a
+// 64-bit division: v = hi * 2^32 + lo, R = 2^32, so v * R = (hi * R) * R + lo * R (mod p) -- three Montgomery products, each
+// with R^2 < p as one factor and an arbitrary u32 as the other.  Equals to_mont(v % p).
+SMI_HD uint32_t to_mont_u64(uint64_t v, const Fp &F) {
+    const uint32_t hi_m = mont_mul(mont_mul((uint32_t)(v >> 32), F.r2, F), F.r2, F);
+    return fp_add(hi_m, mont_mul((uint32_t)v, F.r2, F), F.p);
+}
+
 // base^e with base in Montgomery form; result in Montgomery form.
 SMI_HD uint32_t mont_pow(uint32_t base_m, uint64_t e, const Fp &F) {
     uint32_t res = F.r1;

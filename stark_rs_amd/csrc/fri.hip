@@ -374,7 +374,7 @@ uint64_t fri_tail_len() {
 }
 int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, size_t len, bool do_query, bool reset_arena,
                    smi_fri_run **run_out, std::vector<uint8_t> *proof_host, uint64_t *top_host, uint8_t *roots_host,
-                   uint64_t *alphas_host, uint64_t *last_host, size_t *last_len) {
+                   uint64_t *alphas_host, uint64_t *last_host, size_t *last_len, const LeafSrc *round0_src) {
     SMI_TRY(smi_fri_check(ctx, cfg));
     if (cfg->domain_length != len) return smi_fail(ctx, SMI_ERR_CODEWORD_LEN, "initial codeword length does not match domain length");
     const uint32_t p = ctx->fs.F.p;
@@ -444,6 +444,18 @@ int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, si
     // the per-round path spreads a tree's 64-leaf chunks over several CUs).  SMI_FRI_TAIL=<len> overrides
     // (0: never).
     const uint64_t tail_len = fri_tail_len();
+    // The leaves of a round's tree can be computed by the launch that hashes them (LeafSrc, internal.h): the initial
+    // codeword as the caller's weighted column sum (round0_src), every later one as the fold of the round before --
+    // wherever the tree starts with the four-leaves-per-lane kernel (merkle_fuses_leaf_source).  The codeword buffer is
+    // written by that launch; everything downstream reads it as before.
+    LeafSrc pending;
+    memset(&pending, 0, sizeof pending);
+    bool have_pending = false;
+    if (round0_src) {
+        if (!merkle_fuses_leaf_source(len) || !(cur_len > tail_len)) return bail(smi_fail(ctx, SMI_ERR_BAD_ARG, "fri: the initial codeword is too short for a computed leaf source"));
+        pending = *round0_src;
+        have_pending = true;
+    }
     for (uint64_t r = 0; r < R; r++) {
         if (cur_len <= tail_len && R - r <= SMI_FRI_TAIL_MAX_ROUNDS) {
             // every remaining round in one workgroup launch (hash.hip, fri_tail_kernel)
@@ -492,15 +504,40 @@ int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, si
         // push root, absorb, challenge (src/fri.rs:129-138): done by the workgroup that finishes the tree
         // when that is the chunk kernel (one launch fewer per round), by a kernel of its own otherwise
         bool fs_done = false;
-        if ((rc = launch_merkle_fs(ctx, cur, cur_len, nodes, d_fs->s, run->d_proof + off_roots + 33 * r, last ? nullptr : d_alphas + r,
-                                   &fs_done)) != SMI_OK)
-            return bail(rc);
+        if (have_pending) {
+            rc = launch_merkle_src_fs(ctx, pending, cur_len, nodes, d_fs->s, run->d_proof + off_roots + 33 * r, last ? nullptr : d_alphas + r, &fs_done);
+            have_pending = false;
+        } else {
+            rc = launch_merkle_fs(ctx, cur, cur_len, nodes, d_fs->s, run->d_proof + off_roots + 33 * r, last ? nullptr : d_alphas + r, &fs_done);
+        }
+        if (rc != SMI_OK) return bail(rc);
         if (!fs_done)
             fs_round_kernel<<<1, 64, 0, ctx->stream>>>(d_fs, root, run->d_proof + off_roots + 33 * r, last ? nullptr : d_alphas + r);
         if (last) break;
         uint32_t *next = (uint32_t *)run_alloc(run, (cur_len / 2) * 4);
         if (!next) return bail(smi_fail(ctx, SMI_ERR_OOM, "alloc codeword"));
-        if ((rc = launch_fold(ctx, cur, cur_len, d_alphas + r, offset, omega, next)) != SMI_OK) {
+        const uint64_t next_len = cur_len / 2;
+        const bool next_is_tail = next_len <= tail_len && R - (r + 1) <= SMI_FRI_TAIL_MAX_ROUNDS;
+        if (merkle_fuses_leaf_source(next_len) && !next_is_tail) {
+            // no fold launch: the next round's leaf kernel folds (same checks and tables as launch_fold_shard)
+            if (offset == 0 || omega == 0) {
+                if (!run->arena) (void)hipFree(next);
+                return bail(smi_fail(ctx, SMI_ERR_DIV_BY_ZERO, "no division by zero"));   // src/ff.rs:182
+            }
+            memset(&pending, 0, sizeof pending);
+            pending.kind = LEAF_FOLD;
+            pending.cw_out = next;
+            pending.F = ctx->fs.F;
+            pending.lo = cur;
+            pending.hi = cur + next_len;
+            pending.alpha = d_alphas + r;
+            pending.inv2_m = (uint32_t)(((uint64_t)h_inv(ctx, 2) << 32) % p);
+            if ((rc = ctx_scale_tables(ctx, h_inv(ctx, offset), h_inv(ctx, omega), ilog2(next_len), &pending.S)) != SMI_OK) {
+                if (!run->arena) (void)hipFree(next);
+                return bail(rc);
+            }
+            have_pending = true;
+        } else if ((rc = launch_fold(ctx, cur, cur_len, d_alphas + r, offset, omega, next)) != SMI_OK) {
             if (!run->arena) (void)hipFree(next);
             return bail(rc);
         }
@@ -599,7 +636,7 @@ int smi_dev_fri_prove(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_co
     if (!ctx || !cfg || !d_codeword || !proof || !proof_len) return SMI_ERR_BAD_ARG;
     DeviceGuard dg__(ctx);
     std::vector<uint8_t> bytes;
-    SMI_TRY(fri_run(ctx, cfg, d_codeword, len, true, true, run, &bytes, top_indices, nullptr, nullptr, nullptr, nullptr));
+    SMI_TRY(fri_run(ctx, cfg, d_codeword, len, true, true, run, &bytes, top_indices, nullptr, nullptr, nullptr, nullptr, nullptr));
     *proof = (uint8_t *)malloc(bytes.size() ? bytes.size() : 1);
     if (!*proof) return smi_fail(ctx, SMI_ERR_OOM, "malloc proof");
     memcpy(*proof, bytes.data(), bytes.size());
@@ -635,7 +672,7 @@ int smi_fri_commit(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint64_t *codewor
     uint32_t *d_cw = nullptr;
     int rc = upload_codeword(ctx, codeword, len, &d_cw);
     smi_fri_run *r = nullptr;
-    if (rc == SMI_OK) rc = fri_run(ctx, cfg, d_cw, len, false, true, run ? &r : nullptr, nullptr, nullptr, roots, alphas, last_codeword, last_len);
+    if (rc == SMI_OK) rc = fri_run(ctx, cfg, d_cw, len, false, true, run ? &r : nullptr, nullptr, nullptr, roots, alphas, last_codeword, last_len, nullptr);
     (void)hipStreamSynchronize(ctx->stream);
     if (rc == SMI_OK && run) {
         r->owns_first = true;  // the run keeps the uploaded codeword

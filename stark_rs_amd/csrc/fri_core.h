@@ -13,5 +13,5 @@ SMI_HD uint32_t fold_element(uint32_t lo, uint32_t hi, uint32_t i, uint32_t ah_m
     return fp_add(mont_mul(s, inv2_m, F), mont_mul(d, t_m, F), F.p);
 }
 SMI_HD uint32_t fold_alpha_half(uint64_t alpha, uint32_t inv2_m, const Fp &F) {
-    return mont_mul(to_mont((uint32_t)(alpha % F.p), F), inv2_m, F);   // alpha may be an unreduced u64 (H6)
+    return mont_mul(to_mont_u64(alpha, F), inv2_m, F);   // alpha may be an unreduced u64 (H6); no 64-bit division per thread
 }

@@ -25,11 +25,41 @@ __device__ __forceinline__ size_t level_offset(size_t n, uint32_t lvl) { return 
 // KT > 0: the number of levels per lane is a compile-time constant (the loops below unroll, the stash
 // slots become constants); KT = 0: taken from the argument.  ROWS: the row-leaf path (runtime width) is
 // compiled in -- the element-leaf instantiation the prover lives in carries neither.
-template <bool FROM_ELEMS, int KT, bool ROWS>
+// The four leaves of a lane when they are computed rather than read (LeafSrc, internal.h): stored to the codeword and returned.
+template <int LEAF> __device__ __forceinline__ void leaf_values(const LeafSrc &src, const uint32_t *elems, size_t first, uint32_t (&v)[4]) {
+    if constexpr (LEAF == LEAF_LOAD) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = elems[first + k];
+    } else if constexpr (LEAF == LEAF_FOLD) {
+        const uint32_t ah_m = fold_alpha_half(*src.alpha, src.inv2_m, src.F);
+        const uint4 lo = *(const uint4 *)(src.lo + first), hi = *(const uint4 *)(src.hi + first);     // first is a multiple of 4
+        v[0] = fold_element(lo.x, hi.x, (uint32_t)first, ah_m, src.inv2_m, src.S, src.F);
+        v[1] = fold_element(lo.y, hi.y, (uint32_t)first + 1, ah_m, src.inv2_m, src.S, src.F);
+        v[2] = fold_element(lo.z, hi.z, (uint32_t)first + 2, ah_m, src.inv2_m, src.S, src.F);
+        v[3] = fold_element(lo.w, hi.w, (uint32_t)first + 3, ah_m, src.inv2_m, src.S, src.F);
+        *(uint4 *)(src.cw_out + first) = make_uint4(v[0], v[1], v[2], v[3]);
+    } else {
+        v[0] = v[1] = v[2] = v[3] = 0;
+#pragma unroll
+        for (uint32_t c = 0; c < SMI_LEAF_COMBINE_MAX; c++) {
+            if (c >= src.n_cols) break;
+            const uint32_t w_m = to_mont_u64(src.weights[c], src.F);   // (weights[c] mod p) in Montgomery form
+            const uint4 x = *(const uint4 *)(src.cols + c * src.stride + first);
+            v[0] = fp_add(v[0], mont_mul(x.x, w_m, src.F), src.F.p);
+            v[1] = fp_add(v[1], mont_mul(x.y, w_m, src.F), src.F.p);
+            v[2] = fp_add(v[2], mont_mul(x.z, w_m, src.F), src.F.p);
+            v[3] = fp_add(v[3], mont_mul(x.w, w_m, src.F), src.F.p);
+        }
+        *(uint4 *)(src.cw_out + first) = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+template <bool FROM_ELEMS, int KT, bool ROWS, int LEAF = LEAF_LOAD>
 __global__ __launch_bounds__(SMI_HASH_THREADS) void merkle_sub_kernel(const uint32_t *__restrict__ elems, uint4 *nodes,
                                                                         size_t n, uint32_t lvl_in, size_t count_in,
                                                                         uint32_t K_arg, size_t elem_stride, size_t node_stride,
-                                                                        uint32_t row_cols, size_t row_stride) {
+                                                                        uint32_t row_cols, size_t row_stride, const LeafSrc src) {
+    static_assert(LEAF == LEAF_LOAD || (FROM_ELEMS && KT == 2 && !ROWS), "computed leaves: the four-leaves-per-lane kernel only");
     const uint32_t K = KT ? (uint32_t)KT : K_arg;
     extern __shared__ __attribute__((aligned(16))) uint32_t stash[];  // [1<<K][8][SMI_HASH_THREADS]
     // blockIdx.y = tree of a batch of equally sized trees (e.g. the columns of a trace)
@@ -62,13 +92,15 @@ __global__ __launch_bounds__(SMI_HASH_THREADS) void merkle_sub_kernel(const uint
         };
         uint32_t l0[8], r0[8], l1[8], r1[8];
         if constexpr (FROM_ELEMS) {
+            uint32_t ev[4];
+            leaf_values<LEAF>(src, elems, first, ev);
             {
                 uint32_t d0[8], d1[8];
-                hashc::leaf_hash2(elems[first], elems[first + 1], d0, d1);
+                hashc::leaf_hash2(ev[0], ev[1], d0, d1);
                 put(nodes + 2 * first, 0, d0);
                 put(nodes + 2 * (first + 1), 1, d1);
             }
-            hashc::leaf_hash2(elems[first + 2], elems[first + 3], l1, r1);
+            hashc::leaf_hash2(ev[2], ev[3], l1, r1);
             store(nodes + 2 * (first + 2), l1);
             store(nodes + 2 * (first + 3), r1);
             get(0, l0);
@@ -470,7 +502,8 @@ static uint32_t log2_floor(size_t n) {
 int launch_merkle_batch(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_nodes, uint32_t n_trees, size_t elem_stride,
                         size_t node_stride_bytes, uint32_t row_cols = 0, size_t row_stride = 0);
 static int launch_merkle_impl(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_nodes, uint32_t n_trees, size_t elem_stride,
-                              size_t node_stride_bytes, uint32_t row_cols, size_t row_stride, const TopHook *hook, bool *hook_done);
+                              size_t node_stride_bytes, uint32_t row_cols, size_t row_stride, const TopHook *hook, bool *hook_done,
+                              const LeafSrc *src = nullptr);
 int launch_merkle(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_nodes) {
     return launch_merkle_batch(ctx, d_elems, n, d_nodes, 1, 0, 0);
 }
@@ -481,6 +514,27 @@ int launch_merkle_fs(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d
     const TopHook hook{fs_words, proof_slot, alpha_out};
     *done = false;
     return launch_merkle_impl(ctx, d_elems, n, d_nodes, 1, 0, 0, 0, 0, &hook, done);
+}
+// The planner's rule, restated: with more than 2048 * TOP_BLOCKS leaves the first launch of a single tree is the
+// four-leaves-per-lane kernel (the chunk kernel takes over below that), and that kernel can compute its leaves (LeafSrc).
+static size_t merkle_top_blocks() {
+    static const size_t v = [] { const char *e = getenv("SMI_MERKLE_TOP_BLOCKS"); return (size_t)(e ? atoi(e) : 256); }();
+    return v;
+}
+bool merkle_fuses_leaf_source(size_t n) {
+    static const bool off = (getenv("SMI_MERKLE_FUSE") && atoi(getenv("SMI_MERKLE_FUSE")) == 0) ||
+                            (getenv("SMI_MERKLE_GENERIC") && atoi(getenv("SMI_MERKLE_GENERIC"))) ||
+                            (getenv("SMI_MERKLE_K") && atoi(getenv("SMI_MERKLE_K")) != 2);
+    return !off && n >= 8 && (n & (n - 1)) == 0 && n > (size_t)SMI_TOP_MAX * merkle_top_blocks();
+}
+// one tree whose leaves are computed by the launch that hashes them (src.cw_out receives the codeword)
+int launch_merkle_src_fs(smi_ctx *ctx, const LeafSrc &src, size_t n, uint8_t *d_nodes, uint32_t *fs_words, uint8_t *proof_slot,
+                         uint64_t *alpha_out, bool *done) {
+    if (!merkle_fuses_leaf_source(n) || !src.cw_out || (src.kind == LEAF_COMBINE && (!src.n_cols || src.n_cols > SMI_LEAF_COMBINE_MAX)))
+        return smi_fail(ctx, SMI_ERR_BAD_ARG, "merkle: this tree cannot take a computed leaf source");
+    const TopHook hook{fs_words, proof_slot, alpha_out};
+    *done = false;
+    return launch_merkle_impl(ctx, src.cw_out, n, d_nodes, 1, 0, 0, 0, 0, &hook, done, &src);
 }
 // one tree whose leaf i hashes row i of n_cols columns (column c at d_cols + c*col_stride)
 int launch_merkle_rows(smi_ctx *ctx, const uint32_t *d_cols, uint32_t n_cols, size_t col_stride, size_t n, uint8_t *d_nodes) {
@@ -497,8 +551,11 @@ int launch_merkle_batch(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t
     return launch_merkle_impl(ctx, d_elems, n, d_nodes, n_trees, elem_stride, node_stride_bytes, row_cols, row_stride, nullptr, nullptr);
 }
 static int launch_merkle_impl(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_nodes, uint32_t n_trees, size_t elem_stride,
-                              size_t node_stride_bytes, uint32_t row_cols, size_t row_stride, const TopHook *hook, bool *hook_done) {
+                              size_t node_stride_bytes, uint32_t row_cols, size_t row_stride, const TopHook *hook, bool *hook_done,
+                              const LeafSrc *src) {
     if (!n_trees) return SMI_OK;
+    LeafSrc none;
+    memset(&none, 0, sizeof none);
     const size_t node_stride = node_stride_bytes / 16;
     const uint32_t depth = log2_floor(n);
     uint4 *nodes = (uint4 *)d_nodes;
@@ -511,10 +568,7 @@ static int launch_merkle_impl(smi_ctx *ctx, const uint32_t *d_elems, size_t n, u
         return (uint32_t)(k < 1 ? 1 : (k > 3 ? 3 : k));
     }();
     // chunk workgroups per launch below which the chunk kernel takes over (one per CU; tuning knob)
-    const size_t TOP_BLOCKS = [] {
-        const char *e = getenv("SMI_MERKLE_TOP_BLOCKS");
-        return (size_t)(e ? atoi(e) : 256);
-    }();
+    const size_t TOP_BLOCKS = merkle_top_blocks();
     if (from_elems && depth == 0 && !row_cols) {
         for (uint32_t y = 0; y < n_trees; y++) SMI_TRY(launch_leaf_hash(ctx, d_elems + y * elem_stride, 1, d_nodes + y * node_stride_bytes));
         return SMI_OK;
@@ -572,15 +626,21 @@ static int launch_merkle_impl(smi_ctx *ctx, const uint32_t *d_elems, size_t n, u
         // the hot shapes (element leaves or digests, two levels per lane) have instantiations of their own
         static const bool generic_only = getenv("SMI_MERKLE_GENERIC") && atoi(getenv("SMI_MERKLE_GENERIC"));
         if (from_elems && row_cols)
-            merkle_sub_kernel<true, 0, true><<<grid, SMI_HASH_THREADS, lds, ctx->stream>>>(d_elems, nodes, n, 0, count, K, elem_stride, node_stride, row_cols, row_stride);
+            merkle_sub_kernel<true, 0, true><<<grid, SMI_HASH_THREADS, lds, ctx->stream>>>(d_elems, nodes, n, 0, count, K, elem_stride, node_stride, row_cols, row_stride, none);
+        else if (from_elems && K == 2 && !generic_only && src && src->kind == LEAF_FOLD)   // leaves computed on the fly (LeafSrc)
+            merkle_sub_kernel<true, 2, false, LEAF_FOLD><<<grid, SMI_HASH_THREADS, (size_t)16 * SMI_HASH_THREADS * sizeof(uint32_t), ctx->stream>>>(d_elems, nodes, n, 0, count, K, elem_stride, node_stride, 0, 0, *src);
+        else if (from_elems && K == 2 && !generic_only && src && src->kind == LEAF_COMBINE)
+            merkle_sub_kernel<true, 2, false, LEAF_COMBINE><<<grid, SMI_HASH_THREADS, (size_t)16 * SMI_HASH_THREADS * sizeof(uint32_t), ctx->stream>>>(d_elems, nodes, n, 0, count, K, elem_stride, node_stride, 0, 0, *src);
+        else if (src && from_elems)
+            return smi_fail(ctx, SMI_ERR_BAD_ARG, "merkle: computed leaves need the four-leaves-per-lane kernel");
         else if (from_elems && K == 2 && !generic_only)   // its stash holds two digests per lane
-            merkle_sub_kernel<true, 2, false><<<grid, SMI_HASH_THREADS, (size_t)16 * SMI_HASH_THREADS * sizeof(uint32_t), ctx->stream>>>(d_elems, nodes, n, 0, count, K, elem_stride, node_stride, 0, 0);
+            merkle_sub_kernel<true, 2, false><<<grid, SMI_HASH_THREADS, (size_t)16 * SMI_HASH_THREADS * sizeof(uint32_t), ctx->stream>>>(d_elems, nodes, n, 0, count, K, elem_stride, node_stride, 0, 0, none);
         else if (from_elems)
-            merkle_sub_kernel<true, 0, false><<<grid, SMI_HASH_THREADS, lds, ctx->stream>>>(d_elems, nodes, n, 0, count, K, elem_stride, node_stride, 0, 0);
+            merkle_sub_kernel<true, 0, false><<<grid, SMI_HASH_THREADS, lds, ctx->stream>>>(d_elems, nodes, n, 0, count, K, elem_stride, node_stride, 0, 0, none);
         else if (K == 2 && !generic_only)                 // no stash at all
-            merkle_sub_kernel<false, 2, false><<<grid, SMI_HASH_THREADS, 0, ctx->stream>>>(nullptr, nodes, n, lvl, count, K, 0, node_stride, 0, 0);
+            merkle_sub_kernel<false, 2, false><<<grid, SMI_HASH_THREADS, 0, ctx->stream>>>(nullptr, nodes, n, lvl, count, K, 0, node_stride, 0, 0, none);
         else
-            merkle_sub_kernel<false, 0, false><<<grid, SMI_HASH_THREADS, lds, ctx->stream>>>(nullptr, nodes, n, lvl, count, K, 0, node_stride, 0, 0);
+            merkle_sub_kernel<false, 0, false><<<grid, SMI_HASH_THREADS, lds, ctx->stream>>>(nullptr, nodes, n, lvl, count, K, 0, node_stride, 0, 0, none);
         HIP_TRY(ctx, hipGetLastError());
         from_elems = false;
         lvl += K;

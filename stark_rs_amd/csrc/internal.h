@@ -193,6 +193,35 @@ struct FriTailArgs {
 int launch_fri_tail(smi_ctx *ctx, const FriTailArgs &a);
 uint64_t fri_tail_len();   // codewords of at most this many elements finish in the fused tail (SMI_FRI_TAIL, default 512; fri.hip)
 
+// Where the leaves of a tree come from when they are not simply read (hash.hip, merkle_sub_kernel's LEAF_* kinds): the
+// kernel computes the codeword element, stores it to cw_out (the query phase and the next fold read it) and hashes it.
+// The hash kernels are bound by integer issue and leave HBM idle, so the fold's / the combination's reads and writes ride
+// along for the price of their few arithmetic instructions -- one launch and one pass over the codeword less per round.
+//   LEAF_FOLD   : element i = Fri::fold_codeword(lo[i], hi[i]) (src/fri.rs:57-91; fri_core.h fold_element, the function the
+//                 stand-alone fri_fold_kernel runs) with the round's challenge read from device memory;
+//   LEAF_COMBINE: element i = sum_c (weights[c] mod p) * cols[c * stride + i] (combine_columns_kernel's sum, same order).
+enum { LEAF_LOAD = 0, LEAF_FOLD = 1, LEAF_COMBINE = 2 };
+#define SMI_LEAF_COMBINE_MAX 8
+struct LeafSrc {
+    int kind;
+    uint32_t *cw_out;
+    Fp F;
+    // LEAF_FOLD
+    const uint32_t *lo, *hi;
+    const uint64_t *alpha;
+    ScaleTables S;
+    uint32_t inv2_m;
+    // LEAF_COMBINE
+    const uint32_t *cols;
+    size_t stride;
+    uint32_t n_cols;
+    const uint64_t *weights;
+};
+// true when a tree of n single-element leaves starts with the thread-per-four-leaves kernel that can take a LeafSrc
+bool merkle_fuses_leaf_source(size_t n);
+int launch_merkle_src_fs(smi_ctx *ctx, const LeafSrc &src, size_t n, uint8_t *d_nodes, uint32_t *fs_words, uint8_t *proof_slot,
+                         uint64_t *alpha_out, bool *done);
+
 // launches (defined in the .hip files)
 int launch_geom_table(smi_ctx *ctx, const GeomSpec &s, uint32_t *d_out);
 int launch_narrow(smi_ctx *ctx, const uint64_t *d_in, uint32_t *d_out, size_t n, int reduce);

@@ -23,7 +23,7 @@ int launch_merkle_batch(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t
 int launch_merkle_rows(smi_ctx *ctx, const uint32_t *d_cols, uint32_t n_cols, size_t col_stride, size_t n, uint8_t *d_nodes);
 int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, size_t len, bool do_query, bool reset_arena,
             smi_fri_run **run_out, std::vector<uint8_t> *proof_host, uint64_t *top_host, uint8_t *roots_host,
-            uint64_t *alphas_host, uint64_t *last_host, size_t *last_len);
+            uint64_t *alphas_host, uint64_t *last_host, size_t *last_len, const LeafSrc *round0_src);
 
 // weights[c] = FiatShamir::challenge after absorbing roots[0..c] (unreduced u64)
 __global__ void fs_weights_kernel(const uint8_t *const *root_ptrs, uint32_t n, uint64_t *weights, uint32_t *roots_out) {
@@ -159,7 +159,22 @@ int smi_dev_stark_prove(smi_ctx *ctx, const smi_stark_cfg *cfg, const uint32_t *
         fs_weights_kernel<<<1, 64, 0, ctx->stream>>>(d_rootp, W, d_weights, (uint32_t *)d_roots);
     }
     HIP_TRY(ctx, hipGetLastError());
-    SMI_TRY(smi_dev_combine_columns(ctx, d_lde, W, N, N, d_weights, d_cw));
+    // Sum_c weight_c * col_c: by a kernel of its own, or -- when the first FRI tree starts with the four-leaves-per-lane
+    // kernel -- by that kernel as it hashes (LeafSrc, internal.h): one launch and one pass over the codeword less
+    LeafSrc csrc;
+    memset(&csrc, 0, sizeof csrc);
+    const bool fuse_combine = merkle_fuses_leaf_source(N) && W <= SMI_LEAF_COMBINE_MAX && N > fri_tail_len();
+    if (fuse_combine) {
+        csrc.kind = LEAF_COMBINE;
+        csrc.cw_out = d_cw;
+        csrc.F = ctx->fs.F;
+        csrc.cols = d_lde;
+        csrc.stride = N;
+        csrc.n_cols = W;
+        csrc.weights = d_weights;
+    } else {
+        SMI_TRY(smi_dev_combine_columns(ctx, d_lde, W, N, N, d_weights, d_cw));
+    }
     mark(3);
     smi_fri_cfg fc;
     fc.omega = h_root(ctx, log_N);
@@ -176,7 +191,8 @@ int smi_dev_stark_prove(smi_ctx *ctx, const smi_stark_cfg *cfg, const uint32_t *
         ctx->ride_bytes = 32 * (size_t)T;
         ctx->ride_dst = column_roots;
     }
-    const int fri_rc = fri_run(ctx, &fc, d_cw, N, true, false, nullptr, &bytes, top_indices, nullptr, nullptr, nullptr, nullptr);
+    const int fri_rc = fri_run(ctx, &fc, d_cw, N, true, false, nullptr, &bytes, top_indices, nullptr, nullptr, nullptr, nullptr,
+                               fuse_combine ? &csrc : nullptr);
     ctx->ride_src = nullptr;   // not consumed if fri_run failed early
     ctx->ride_bytes = 0;
     ctx->ride_dst = nullptr;

@@ -204,6 +204,62 @@ def test_full_size_fri_prove_accepted_by_oracle_verify(eng, oracle):
     assert not o.fri_verify(ocfg, bytes(bad))
 
 
+def test_fri_prove_with_folds_computed_by_the_leaf_kernel_is_byte_identical(eng, oracle):
+    """From 2^20 leaves on, a round's tree kernel computes its own leaves: Fri::fold_codeword of the previous codeword (LeafSrc /
+    LEAF_FOLD, csrc/hash.hip) instead of reading the output of a separate fold launch.  2^21-point codeword: round 1 (2^20
+    leaves) takes that path -- the serialized proof must still be the op-for-op oracle's, byte for byte, and the retained
+    codeword of round 1 the oracle's fold of round 0 with the oracle's challenge."""
+    o = oracle
+    n, exp, t, offset = 1 << 21, 8, 8, 5
+    omega = o.ff_prim_nth_root(n)
+    cw = o.fast_coset_ntt(_vals(o, 77, n // exp), n, omega, offset)
+    cfg_o, cfg_e = o.fri_cfg(omega, offset, n, exp, t), eng.fri_cfg(omega, offset, n, exp, t)
+    want, want_top = o.fri_prove(cfg_o, cw)
+    d = _upload(eng, cw)
+    got, got_top = eng.dev_fri_prove(cfg_e, d, n)
+    eng.dev_free(d)
+    assert list(got_top) == want_top
+    assert bytes(got) == want
+
+
+def test_stark_prove_with_the_combination_computed_by_the_leaf_kernel(eng2, oracle):
+    """2^17 rows x 4 columns at blowup 8 (N = 2^20): the first FRI tree's kernel computes the weighted column sum itself
+    (LEAF_COMBINE) -- the proof must equal the one made step by step through the C ABI with the stand-alone
+    smi_dev_combine_columns (whose own parity with the oracle test_stark_prove_composition checks), and the oracle's
+    Fri::verify must accept it."""
+    import ctypes as C
+    o = oracle
+    e, p, g = eng2, P2, G2
+    logn, lb, W, t = 17, 3, 4, 8
+    n, N = 1 << logn, 1 << (logn + lb)
+    cols = np.stack([_vals(o, 0x5354524B00 + c, n, p) for c in range(W)])
+    d = _upload(e, cols)
+    res = e.dev_stark_prove(d, W, logn, lb, t)
+    # step by step: extension, column roots (Merkle over each column), weights on the host from the roots, combination, Fri::prove
+    d_lde = e.dev_alloc(W * N * 4)
+    e.dev_lde(d, W, logn, lb, d_lde)
+    d_nodes = e.dev_alloc((2 * N - 1) * 32)
+    fs, weights = o.FiatShamir(), []
+    for c in range(W):
+        e.dev_merkle_build(d_lde + c * N * 4, N, d_nodes)
+        e.sync()
+        root = e.dev_download(d_nodes + (2 * N - 2) * 32, 8).astype(np.uint32).tobytes()     # eight LE words = the 32 root bytes
+        assert root == bytes(res["column_roots"][c])
+        fs.absorb(root)
+        weights.append(fs.challenge())                      # unreduced, as the device keeps them
+    import torch
+    t_w = torch.from_numpy(np.array(weights, dtype=np.uint64).view(np.int64)).cuda()
+    d_cw = e.dev_alloc(N * 4)
+    e.dev_combine_columns(d_lde, W, N, N, t_w.data_ptr(), d_cw)
+    Wn = e.prim_nth_root(N)
+    want, want_top = e.dev_fri_prove(e.fri_cfg(Wn, g, N, 1 << lb, t), d_cw, N)
+    assert res["proof"] == bytes(want) and res["top_indices"] == list(want_top)
+    assert o.fri_verify(o.fri_cfg(Wn, g, N, 1 << lb, t, p), res["proof"]), o.fri_last_reject()
+    e.sync()
+    for ptr in (d, d_lde, d_nodes, d_cw):
+        e.dev_free(ptr)
+
+
 def test_cfg5_shape_on_second_prime(eng2, oracle):
     """BASELINE configs[4] shape (2^22 rows x 4 columns, blowup 8 -> 2^25 domain, 18 rounds) on the
     second prime; accepted by the p-generic oracle's Fri::verify."""

@@ -6,7 +6,7 @@ TAG=${1:-run}
 OUT=gpurun_out/stalls_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 bench.py --no-extras --steps 10 --warmup 3"
+BENCH="python3 bench.py --no-extras --in-loop-only --steps 100 --warmup 50"   # sustained regime (r03)
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT -d $OUT/sq -o sq -- $BENCH > /dev/null 2> $OUT/sq.err
 rocprofv3 --kernel-trace --output-format csv --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAVES -d $OUT/grbm -o g -- $BENCH > /dev/null 2> $OUT/grbm.err
 python3 - $OUT <<'PY'
