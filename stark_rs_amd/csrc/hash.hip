@@ -43,7 +43,7 @@ template <int LEAF> __device__ __forceinline__ void leaf_values(const LeafSrc &s
 #pragma unroll
         for (uint32_t c = 0; c < SMI_LEAF_COMBINE_MAX; c++) {
             if (c >= src.n_cols) break;
-            const uint32_t w_m = to_mont_u64(src.weights[c], src.F);   // (weights[c] mod p) in Montgomery form
+            const uint32_t w_m = src.weights_m[c];   // (weights[c] mod p) in Montgomery form, wave-uniform
             const uint4 x = *(const uint4 *)(src.cols + c * src.stride + first);
             v[0] = fp_add(v[0], mont_mul(x.x, w_m, src.F), src.F.p);
             v[1] = fp_add(v[1], mont_mul(x.y, w_m, src.F), src.F.p);

@@ -215,7 +215,7 @@ struct LeafSrc {
     const uint32_t *cols;
     size_t stride;
     uint32_t n_cols;
-    const uint64_t *weights;
+    const uint32_t *weights_m;   // (weight mod p) in Montgomery form, on the device (fs_weights_kernel)
 };
 // true when a tree of n single-element leaves starts with the thread-per-four-leaves kernel that can take a LeafSrc
 bool merkle_fuses_leaf_source(size_t n);

@@ -26,7 +26,9 @@ int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, si
             uint64_t *alphas_host, uint64_t *last_host, size_t *last_len, const LeafSrc *round0_src);
 
 // weights[c] = FiatShamir::challenge after absorbing roots[0..c] (unreduced u64)
-__global__ void fs_weights_kernel(const uint8_t *const *root_ptrs, uint32_t n, uint64_t *weights, uint32_t *roots_out) {
+// weights_m (optional): the same weights reduced mod p in Montgomery form, what the fused combination multiplies by
+__global__ void fs_weights_kernel(const uint8_t *const *root_ptrs, uint32_t n, uint64_t *weights, uint32_t *roots_out,
+                                  uint32_t *weights_m = nullptr, Fp F = Fp{0, 0, 0, 0}) {
     if (threadIdx.x || blockIdx.x) return;
     hashc::State st;
     hashc::init(st);
@@ -40,6 +42,7 @@ __global__ void fs_weights_kernel(const uint8_t *const *root_ptrs, uint32_t n, u
         uint32_t d[8];
         hashc::to_words(ch, d);
         weights[c] = (uint64_t)d[0] | ((uint64_t)d[1] << 32);
+        if (weights_m) weights_m[c] = to_mont_u64(weights[c], F);
     }
 }
 
@@ -62,7 +65,8 @@ int launch_fs_weights(smi_ctx *ctx, const uint8_t *const *d_root_ptrs, uint32_t 
 
 // row-leaf variant: a single root enters the transcript; weight c = FiatShamir::challenge of the
 // transcript root || c as LE u64 (absorb(root); absorb(c.to_le_bytes()); challenge() on a clone)
-__global__ void fs_row_weights_kernel(const uint8_t *root, uint32_t n, uint64_t *weights, uint8_t *roots_out) {
+__global__ void fs_row_weights_kernel(const uint8_t *root, uint32_t n, uint64_t *weights, uint8_t *roots_out, uint32_t *weights_m = nullptr,
+                                      Fp F = Fp{0, 0, 0, 0}) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
     uint8_t msg[40];
@@ -73,6 +77,7 @@ __global__ void fs_row_weights_kernel(const uint8_t *root, uint32_t n, uint64_t 
     uint32_t d[8];
     hashc::hash_bytes(msg, 40, d);
     weights[c] = (uint64_t)d[0] | ((uint64_t)d[1] << 32);
+    if (weights_m) weights_m[c] = to_mont_u64(weights[c], F);
 }
 
 // out[i] = sum_c (weights[c] mod p) * cols[c*stride + i]      HBM-bound: 4*(n_cols+1) B per element
@@ -132,8 +137,9 @@ int smi_dev_stark_prove(smi_ctx *ctx, const smi_stark_cfg *cfg, const uint32_t *
     uint32_t *d_lde = (uint32_t *)arena_alloc(ctx, (size_t)W * N * 4);
     uint32_t *d_cw = (uint32_t *)arena_alloc(ctx, N * 4);
     uint64_t *d_weights = (uint64_t *)arena_alloc(ctx, 8 * W);
+    uint32_t *d_weights_m = (uint32_t *)arena_alloc(ctx, 4 * W);
     const uint8_t **d_rootp = (const uint8_t **)arena_alloc(ctx, sizeof(void *) * W);
-    if (!d_lde || !d_cw || !d_weights || !d_rootp) return smi_fail(ctx, SMI_ERR_OOM, "stark_prove: device memory");
+    if (!d_lde || !d_cw || !d_weights || !d_weights_m || !d_rootp) return smi_fail(ctx, SMI_ERR_OOM, "stark_prove: device memory");
     std::vector<uint8_t *> trees(W);
     std::vector<const uint8_t *> rootp(W);
     // the W column trees sit back to back (stride 2N digests) so one set of launches builds them all
@@ -153,10 +159,10 @@ int smi_dev_stark_prove(smi_ctx *ctx, const smi_stark_cfg *cfg, const uint32_t *
     uint8_t *d_roots = (uint8_t *)arena_alloc(ctx, 32 * (size_t)T);
     if (!d_roots) return smi_fail(ctx, SMI_ERR_OOM, "stark_prove: device memory");
     if (cfg->row_leaves) {
-        fs_row_weights_kernel<<<1, 64, 0, ctx->stream>>>(rootp[0], W, d_weights, d_roots);
+        fs_row_weights_kernel<<<1, 64, 0, ctx->stream>>>(rootp[0], W, d_weights, d_roots, d_weights_m, ctx->fs.F);
     } else {
         HIP_TRY(ctx, hipMemcpyAsync(d_rootp, rootp.data(), sizeof(void *) * W, hipMemcpyHostToDevice, ctx->stream));
-        fs_weights_kernel<<<1, 64, 0, ctx->stream>>>(d_rootp, W, d_weights, (uint32_t *)d_roots);
+        fs_weights_kernel<<<1, 64, 0, ctx->stream>>>(d_rootp, W, d_weights, (uint32_t *)d_roots, d_weights_m, ctx->fs.F);
     }
     HIP_TRY(ctx, hipGetLastError());
     // Sum_c weight_c * col_c: by a kernel of its own, or -- when the first FRI tree starts with the four-leaves-per-lane
@@ -171,7 +177,7 @@ int smi_dev_stark_prove(smi_ctx *ctx, const smi_stark_cfg *cfg, const uint32_t *
         csrc.cols = d_lde;
         csrc.stride = N;
         csrc.n_cols = W;
-        csrc.weights = d_weights;
+        csrc.weights_m = d_weights_m;
     } else {
         SMI_TRY(smi_dev_combine_columns(ctx, d_lde, W, N, N, d_weights, d_cw));
     }
