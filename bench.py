@@ -478,11 +478,18 @@ def main():
         try:
             for _ in range(2):   # warm-up: the first call sizes the device arena, the second allocates it
                 eng.dev_stark_prove(trace.data_ptr(), N_COLS, LOG_ROWS, LOG_BLOWUP, N_TESTS)
-            barrier()
-            torch.cuda.synchronize()
-            tp = time.perf_counter()
-            res = eng.dev_stark_prove(trace.data_ptr(), N_COLS, LOG_ROWS, LOG_BLOWUP, N_TESTS, timed=True)
-            prove_ms = 1e3 * (time.perf_counter() - tp)
+            # five timed proves, each between its own synchronisations; prove_ms = the median's wall time (host call to
+            # proof bytes on the host), stage times from the same prove
+            runs = []
+            for _ in range(5):
+                barrier()
+                torch.cuda.synchronize()
+                tp = time.perf_counter()
+                res_k = eng.dev_stark_prove(trace.data_ptr(), N_COLS, LOG_ROWS, LOG_BLOWUP, N_TESTS, timed=True)
+                runs.append((1e3 * (time.perf_counter() - tp), res_k))
+            runs.sort(key=lambda x: x[0])
+            prove_ms, res = runs[len(runs) // 2]
+            result["prove_ms_all"] = [x[0] for x in runs]
             if distributed:
                 tt = torch.tensor([prove_ms], dtype=torch.float64, device=dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -26,12 +26,13 @@ def bench_name(sym):
         return f"lde_a_kernel<{m.group(1)}>"
     if "lde_b_kernel" in sym:
         return "lde_b_kernel"
-    m = re.search(r"merkle_sub_kernel<(true|false)(?:, (\d+), (true|false))?>", sym)
+    m = re.search(r"merkle_sub_kernel<(true|false)(?:, (\d+), (true|false)(?:, (\d+))?)?>", sym)
     if m:
         kind = "leaves" if m.group(1) == "true" else "digests"
         if m.group(3) == "true":
             kind = "row leaves"
-        return f"merkle_sub_kernel<{kind}>" + (f" K={m.group(2)}" if m.group(2) and m.group(2) != "0" else "")
+        src = {None: "", "0": "", "1": " fold", "2": " combine"}.get(m.group(4), "")     # LeafSrc kind: leaves computed by the kernel
+        return f"merkle_sub_kernel<{kind}>" + (f" K={m.group(2)}" if m.group(2) and m.group(2) != "0" else "") + src
     m = re.search(r"(\w+_kernel)", sym)
     return m.group(1) if m else sym
 
