@@ -260,6 +260,25 @@ def test_stark_prove_with_the_combination_computed_by_the_leaf_kernel(eng2, orac
         e.dev_free(ptr)
 
 
+def test_mix_probe_and_the_librarys_mix_accounting(eng, oracle):
+    """bench.py's prove_roofline: smi_ctx_mix_probe (the bare permutation's rate, the in-run ceiling) returns a plausible rate,
+    and the per-kernel records count SURVEY 8(d)'s N*9 + (N-1)*10 mix_state evaluations for a tree -- whichever kernels the
+    planner splits it into (chunk kernel only at 2^12, subtree + chunk kernels at 2^20 and 2^21)."""
+    rate = eng.mix_probe(64)
+    assert 5e10 < rate < 5e12
+    for logn in (12, 20, 21):
+        n = 1 << logn
+        d = _upload(eng, _vals(oracle, logn, n))
+        d_nodes = eng.dev_alloc((2 * n - 1) * 32)
+        eng.profile(True)
+        eng.dev_merkle_build(d, n, d_nodes)
+        k = eng.profile_read()
+        eng.profile(False)
+        assert sum(v["alg_mixes"] for v in k.values()) == 9.0 * n + 10.0 * (n - 1), (logn, k)
+        eng.dev_free(d)
+        eng.dev_free(d_nodes)
+
+
 def test_cfg5_shape_on_second_prime(eng2, oracle):
     """BASELINE configs[4] shape (2^22 rows x 4 columns, blowup 8 -> 2^25 domain, 18 rounds) on the
     second prime; accepted by the p-generic oracle's Fri::verify."""
