@@ -518,7 +518,10 @@ int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, si
         if (!next) return bail(smi_fail(ctx, SMI_ERR_OOM, "alloc codeword"));
         const uint64_t next_len = cur_len / 2;
         const bool next_is_tail = next_len <= tail_len && R - (r + 1) <= SMI_FRI_TAIL_MAX_ROUNDS;
-        if (merkle_fuses_leaf_source(next_len) && !next_is_tail) {
+        // (the computed-leaf kernel reads and writes four elements at a time: 16-byte aligned buffers only -- the library's own
+        // are, a caller's initial codeword need not be)
+        const bool aligned16 = (((uintptr_t)cur | (uintptr_t)next) & 15u) == 0;
+        if (merkle_fuses_leaf_source(next_len) && !next_is_tail && aligned16) {
             // no fold launch: the next round's leaf kernel folds (same checks and tables as launch_fold_shard)
             if (offset == 0 || omega == 0) {
                 if (!run->arena) (void)hipFree(next);

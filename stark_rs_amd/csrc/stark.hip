@@ -169,7 +169,8 @@ int smi_dev_stark_prove(smi_ctx *ctx, const smi_stark_cfg *cfg, const uint32_t *
     // kernel -- by that kernel as it hashes (LeafSrc, internal.h): one launch and one pass over the codeword less
     LeafSrc csrc;
     memset(&csrc, 0, sizeof csrc);
-    const bool fuse_combine = merkle_fuses_leaf_source(N) && W <= SMI_LEAF_COMBINE_MAX && N > fri_tail_len();
+    const bool fuse_combine = merkle_fuses_leaf_source(N) && W <= SMI_LEAF_COMBINE_MAX && N > fri_tail_len() &&
+                              (((uintptr_t)d_lde | (uintptr_t)d_cw) & 15u) == 0;   // four elements per access, N is a multiple of 4
     if (fuse_combine) {
         csrc.kind = LEAF_COMBINE;
         csrc.cw_out = d_cw;

@@ -220,6 +220,12 @@ def test_fri_prove_with_folds_computed_by_the_leaf_kernel_is_byte_identical(eng,
     eng.dev_free(d)
     assert list(got_top) == want_top
     assert bytes(got) == want
+    # a caller's codeword that is only 4-byte aligned: the four-at-a-time leaf source must not be used on it (separate fold launch)
+    d2 = eng.dev_alloc((n + 4) * 4)
+    eng.dev_upload(cw, d2 + 4)
+    got2, top2 = eng.dev_fri_prove(cfg_e, d2 + 4, n)
+    eng.dev_free(d2)
+    assert bytes(got2) == want and list(top2) == want_top
 
 
 def test_stark_prove_with_the_combination_computed_by_the_leaf_kernel(eng2, oracle):
