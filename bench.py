@@ -741,6 +741,7 @@ def main():
         # the CPU path beside the GPU numbers, at any world size: rank 0's host cores, one thread (the other ranks
         # wait for it at the process group's teardown)
         enter("cpu_baseline")
+        watchdog.cancel()          # the GPU legs are over: the CPU leg cannot hang on a peer, and its ~15 s must not count against them
         if rank == 0:
             try:
                 result["cpu_baseline"] = cpu_baseline()
