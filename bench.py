@@ -384,7 +384,12 @@ def main():
     eng.profile_only(None)
     alone_ms = alone["total_ms"] / alone["launches"] if alone and alone["launches"] else None
     bracketed_step_ms = sum(k["total_ms"] for k in kernels.values()) / all_steps
-    avg_ms = bracketed_ms * max(1.0, (1e3 * elapsed / args.steps) / bracketed_step_ms)
+    # In the loop the kernels of a step abut (rocprofv3 trace: no gap) and their durations add up to the step time, so the
+    # dominant kernel's in-loop duration is its share of the bracketed step x the un-instrumented ms_per_step.  The scale goes
+    # both ways: in r02's 20-step bursts the bracketed launches ran at a higher clock than the loop (scale > 1); in the
+    # sustained state the event pairs cost the bracketed launches a few percent instead (r03: 257 us bracketed, 237-241 us by
+    # the trace of the same loop), scale < 1.
+    avg_ms = bracketed_ms * (1e3 * elapsed / args.steps) / bracketed_step_ms
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
     # HBM traffic per launch from the PMC passes of tools/profile.sh (rocprofv3 --pmc FETCH_SIZE /
     # WRITE_SIZE in separate runs, gfx950 correction applied there): a measured file committed under
@@ -423,7 +428,7 @@ def main():
     ntt_ms = sum(k["total_ms"] for k in kernels.values()) / all_steps
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc, earlier run of the same command)",
-                "avg_launch_ms": avg_ms, "avg_launch_ms_note": "bracketed duration x (ms_per_step / bracketed step sum)",
+                "avg_launch_ms": avg_ms, "avg_launch_ms_note": "share of the event-bracketed step x un-instrumented ms_per_step (kernels abut in the loop)",
                 "avg_launch_ms_every_launch_bracketed": bracketed_ms, "avg_launch_ms_only_this_kernel_bracketed": alone_ms,
                 "alg_bytes_per_launch": bytes_per_launch,
                 # whole-LDE view: SURVEY 8(d) (12+4B)*n*4 cols algorithmic bytes over the step's kernel time
