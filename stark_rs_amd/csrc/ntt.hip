@@ -70,6 +70,9 @@ __global__ __launch_bounds__(1 << (LOGR + LOGW - 4)) void ntt_pass_kernel(const 
 #ifndef SMI_COLS_TWIN_MQ
 #define SMI_COLS_TWIN_MQ 1
 #endif
+#ifndef SMI_COLS_PREFETCH   // the middle pass's column loop issues the next column's loads under the current column's last step and stores
+#define SMI_COLS_PREFETCH 1  // (r03, profiles/r03_r_prefetch_ab.log, r03_s_prefetch_ab.log: -1.2 ... -1.8 % per step)
+#endif
 template <int LOGR, int LOGW, int KIND, int CAP, bool TWIN = false>   // TWIN: the previous pass left its twiddles to this one (NTT_TW_IN)
 __global__ __launch_bounds__(1 << (LOGR + LOGW - 4), TWIN ? SMI_COLS_TWIN_WAVES : SMI_COLS_WAVES(LOGR + LOGW, LOGR)) void ntt_pass_cols_kernel(const PassArgs a) {
     typedef NttPass<LOGR, LOGW, KIND, CAP> NP;
@@ -84,6 +87,41 @@ __global__ __launch_bounds__(1 << (LOGR + LOGW - 4), TWIN ? SMI_COLS_TWIN_WAVES 
     uint32_t iw[TWIN ? NP::V : 1];
     if constexpr (TWIN) NP::in_mul(a, t, tid0, iw);
     const uint32_t col0 = blockIdx.y * NP::COLS_PER_WG, col1 = min(a.batch, col0 + (uint32_t)NP::COLS_PER_WG);
+    // Software pipeline over the columns of the tile (middle passes with 32 lines per tile: the shapes of the 2^21+ plans,
+    // where it fits the register bound without spilling; the other middle shapes would spill 2..7 registers and keep the
+    // plain loop): once step 0 has moved a column's 16 values from the load registers into LDS those registers are free,
+    // so the NEXT column's loads are issued there and fly under this column's last step and stores (the compiler places the
+    // wait before their first use, at the top of the next iteration).  Same instructions, same results; only the order of
+    // issue changes.  r03, three A/B rounds on one box (profiles/r03_s_prefetch_ab.log): 0.7014-0.7062 -> 0.6955-0.6971 ms
+    // per step; giving the forward transform's last pass (no output scale, one column per workgroup) the same column loop
+    // changes nothing further (0.6964-0.6974) and is not built.
+    if constexpr (SMI_COLS_PREFETCH && KIND == PASS_MID && LOGW == 5) {
+        uint32_t v[NP::V];
+        auto load = [&](uint32_t col) {
+            uint32_t tid = tid0;
+            asm volatile("" : "+v"(tid));   // see below: keeps the tile program's addresses from being hoisted
+            NP::template load_regs<0, !TWIN>(a, t, col, v, tid);
+        };
+        load(col0);
+        for (uint32_t batch = col0; batch < col1; batch++) {
+            uint32_t tid = tid0;
+            asm volatile("" : "+v"(tid));
+            if constexpr (TWIN) {
+#pragma unroll
+                for (int i = 0; i < NP::V; i++) v[i] = mont_mul(v[i], iw[i], a.F);
+            }
+            __syncthreads();                // the previous column's LDS reads are over (first column: the twiddle table is staged)
+            NP::template step0_regs<0>(a, v, tile, tw, tid);
+            if (batch + 1 < col1) load(batch + 1);
+            __syncthreads();
+            if (NP::St::n == 3) {
+                NP::step_mid(a, tile, tw, tid);
+                __syncthreads();
+            }
+            NP::template last_step_store_mul<MQ>(a, t, batch, tile, tw, tid, mw, mq);
+        }
+        return;
+    }
     for (uint32_t batch = col0; batch < col1; batch++) {
         // Opaque per-iteration copy of the thread index: without it every address of the tile program (loop-invariant
         // across the columns) is hoisted and held in registers -- 150 VGPRs, or spills under a bound
