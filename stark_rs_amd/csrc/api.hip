@@ -115,7 +115,6 @@ void smi_ctx_destroy(smi_ctx *ctx) {
     }
     for (uint32_t *t : ctx->d_root_tab) (void)hipFree(t);
     (void)hipFree(ctx->scratch);
-    (void)hipFree(ctx->scratch2);
     (void)hipFree(ctx->arena);
     for (void *q : ctx->arena_overflow) (void)hipFree(q);
     for (int i = 0; i < 4; i++) (void)hipFree(ctx->tmp[i]);
@@ -272,18 +271,6 @@ int ctx_scratch(smi_ctx *ctx, size_t elems, uint32_t **out) {
         ctx->scratch_elems = elems;
     }
     *out = ctx->scratch;
-    return SMI_OK;
-}
-int ctx_scratch2(smi_ctx *ctx, size_t elems, uint32_t **out) {
-    if (elems > ctx->scratch2_elems) {
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        (void)hipFree(ctx->scratch2);
-        ctx->scratch2 = nullptr;
-        ctx->scratch2_elems = 0;
-        if (hipMalloc((void **)&ctx->scratch2, elems * 4) != hipSuccess) return smi_fail(ctx, SMI_ERR_OOM, "hipMalloc NTT scratch (second)");
-        ctx->scratch2_elems = elems;
-    }
-    *out = ctx->scratch2;
     return SMI_OK;
 }
 NttTables ctx_tables(const smi_ctx *ctx, int inverse) {

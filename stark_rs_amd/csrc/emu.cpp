@@ -153,8 +153,6 @@ extern "C" void emu_set_last_direct(int on) { g_emu_last_direct = on != 0; }
 static int g_emu_defer_tw = 2;   // NttRequest::defer_tw: 0 never, 1 always, 2 the driver's rule
 extern "C" void emu_set_defer_tw(int mode) { g_emu_defer_tw = mode; }
 extern "C" void emu_set_share_cols(int mode) { g_share_cols = mode; }
-static int g_emu_tile_major = 0;         // NttRequest::tile_major (the product's default: natural order)
-extern "C" void emu_set_tile_major(int mode) { g_emu_tile_major = mode; }
 extern "C" int emu_ntt(uint64_t p, uint64_t g, const uint32_t *in, uint32_t *out, uint32_t L, uint32_t n_in,
                        uint32_t batch, uint64_t in_stride, uint64_t out_stride, int inverse, uint64_t offset,
                        uint64_t post_scale) {
@@ -187,10 +185,8 @@ extern "C" int emu_ntt(uint64_t p, uint64_t g, const uint32_t *in, uint32_t *out
         slo = fill(s2[0], F); shi = fill(s2[1], F);
     }
     rq.S = ScaleTables{slo.data(), shi.data(), scale_table_h(L)};
-    std::vector<uint32_t> scratch((size_t)batch << L), scratch2(g_emu_tile_major ? ((size_t)batch << L) : 0);
+    std::vector<uint32_t> scratch((size_t)batch << L);
     rq.in = in; rq.out = out; rq.scratch = scratch.data();
-    rq.scratch2 = g_emu_tile_major ? scratch2.data() : nullptr;
-    rq.tile_major = g_emu_tile_major;
     rq.L = L; rq.n_in = n_in; rq.batch = batch; rq.in_stride = in_stride; rq.out_stride = out_stride; rq.F = F;
     rq.defer_tw = g_emu_defer_tw;
     rq.last_direct = g_emu_last_direct;

@@ -37,11 +37,6 @@ struct smi_ctx {
     uint32_t *d_root_tab[32] = {};   // [log m]: w_m^e, e < m, as (value, Shoup quotient) pairs (ctx_root_table)
     uint32_t *scratch = nullptr;   // NTT inter-pass buffer
     size_t scratch_elems = 0;
-    uint32_t *scratch2 = nullptr;  // second inter-pass buffer of three-pass transforms (tile-major intermediates, ntt_driver.h)
-    size_t scratch2_elems = 0;
-    // NttRequest::tile_major; tuning knob, default 0: measured r03 (profiles/r03_g_tile_major_ab.log) the contiguous loads it
-    // buys are paid for by the producing pass's more scattered stores -- 0.705-0.711 ms per step against 0.692-0.704
-    int ntt_tile_major = getenv("SMI_NTT_TILE_MAJOR") ? atoi(getenv("SMI_NTT_TILE_MAJOR")) : 0;
     void *tmp[4] = {nullptr, nullptr, nullptr, nullptr};  // staging buffers of the host-buffer entry points
     size_t tmp_bytes[4] = {0, 0, 0, 0};
     int *d_flag = nullptr;         // non-canonical input flag
@@ -135,7 +130,6 @@ int smi_fail(smi_ctx *ctx, int code, const char *msg);
 // grows (never shrinks) a context-owned staging buffer
 int ctx_tmp(smi_ctx *ctx, int slot, size_t bytes, void **out);
 int ctx_scratch(smi_ctx *ctx, size_t elems, uint32_t **out);
-int ctx_scratch2(smi_ctx *ctx, size_t elems, uint32_t **out);
 // Pinned host memory for the results a prove copies back (grows, never shrinks): a device-to-host copy into pageable
 // memory is staged and blocks per call (r03 trace: 6 copies, 105 us of idle at the end of a prove); into pinned
 // memory the copies queue behind the last kernel and one synchronisation waits for all of them.

@@ -194,15 +194,12 @@ __global__ __launch_bounds__(1 << (LOGR + LOGW - 4)) void ntt_copy_probe_kernel(
         for (int i = 0; i < NP::V; i++) st32(a.out + lin_out, (uint32_t)i * NP::NT + tid, v[i] + 1u);
         return;
     }
-    // the pass's own store addresses (natural order or the next pass's tile-major order, NttPass::out_map)
-    typename NP::OutMap om{t.out_base + (tid & (NP::W - 1)), a.Sp};
-    if constexpr (KIND != PASS_LAST) om = NP::out_map(a, t, tid & (NP::W - 1));
-    uint32_t *out = a.out + (uint64_t)batch * a.out_stride + om.base;
-    const uint32_t sh = om.klog;   // stride of the frequency index in the output
+    uint32_t *out = a.out + (uint64_t)batch * a.out_stride + t.out_base;
+    const uint32_t sh = KIND == PASS_LAST ? a.Sp : a.L - a.Sp - LOGR;   // stride of the frequency index in the output
 #pragma unroll
     for (int bi = 0; bi < NB; bi++) {
         const uint32_t u = tid + bi * NP::NT;
-        const uint32_t o0 = NP::blk_to_k(u >> LOGW) << sh;
+        const uint32_t o0 = (NP::blk_to_k(u >> LOGW) << sh) + (u & (NP::W - 1));
 #pragma unroll
         for (int kk = 0; kk < NP::RL; kk++) st32(out, o0 + ((uint32_t)kk << (KSTEP_LOG + sh)), v[bi * NP::RL + kk] + 1u);
     }
@@ -509,10 +506,7 @@ int dev_ntt(smi_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint32_t log_n,
     }
     rq.defer_tw = ctx->ntt_defer_tw;
     rq.last_direct = ctx->ntt_last_direct;
-    const int np = ntt_make_plan(log_n, batch).np;
-    if (np > 0) SMI_TRY(ctx_scratch(ctx, (size_t)batch << log_n, &rq.scratch));   // inter-pass buffer
-    rq.tile_major = ctx->ntt_tile_major;
-    if (np == 3 && rq.tile_major) SMI_TRY(ctx_scratch2(ctx, (size_t)batch << log_n, &rq.scratch2));   // tile-major intermediates
+    if (ntt_make_plan(log_n, batch).np > 0) SMI_TRY(ctx_scratch(ctx, (size_t)batch << log_n, &rq.scratch));   // inter-pass buffer
     HipLauncher ln{ctx};
     if (!ntt_run(ln, rq)) return smi_fail(ctx, SMI_ERR_BAD_ARG, "ntt: multi-pass plan without its inter-pass buffer");
     if (ln.err != hipSuccess) return smi_hip_fail(ctx, ln.err, "ntt kernel launch");

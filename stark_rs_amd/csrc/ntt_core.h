@@ -91,18 +91,6 @@ struct PassArgs {
     // of an extension is bound by arithmetic, the middle one by memory.  prev_logr = log2 of the
     // previous pass's digit (k = sub-problem index mod 2^prev_logr).
     uint32_t prev_logr;
-    // Tile-major inter-pass layout (three-pass plans, ntt_driver.h).  The buffer between two passes belongs to the
-    // transform, so its layout is free: the producing pass stores every element where the CONSUMING pass's tile is one
-    // contiguous run (its 16 loads per thread become tid + i * NT of a 32 KB block instead of 128-byte pieces 1 KB or
-    // 256 KB apart: copy-only twins of the 2^25 x 4 passes 209 -> 185 us and 236 -> 211 us, profiles/r03_f_probe_linear.log).
-    //   in_tm : this pass's input is in its own tile-major order;
-    //   out_tm: 1 = the next pass is a strided pass with digit 2^nx_logr and 2^nx_logw lines per tile: inside a row
-    //               (r' | b'hi | b'lo) becomes (b'hi | r' | b'lo);
-    //           2 = the next pass is the last one and this one the only middle pass: [k_0][k_1][r] becomes
-    //               [k_1][k_0][r], so that the last pass's W lines (adjacent k_0) are adjacent in memory.
-    // A pass no longer transforms in place then (its tile's reads and writes are different sets): the driver gives it
-    // distinct input and output buffers.
-    uint32_t in_tm, out_tm, nx_logr, nx_logw;
 };
 
 // digit structure of the in-tile transform; s0 = 4 everywhere, so the 16 values a thread loads in
@@ -243,9 +231,7 @@ template <int LOGR, int LOGW, int KIND, int CAP> struct NttPass {
 
     struct TileId {  // wave-uniform description of the tile this workgroup owns
         uint64_t in_base, out_base;  // element offsets of line 0 / output run 0 (within the column)
-        uint64_t in_lin;             // PassArgs::in_tm: offset of the tile's contiguous block
         uint32_t b0;                 // first inner column (strided passes) / first k_0 (last pass)
-        uint32_t sub;                // strided passes: index of the sub-problem (the digits consumed so far)
     };
 
     static SMI_HD TileId tile_id(const PassArgs &a, uint32_t block) {
@@ -256,10 +242,8 @@ template <int LOGR, int LOGW, int KIND, int CAP> struct NttPass {
             const uint32_t tpa = 1u << (ablog - LOGW);                // tiles per sub-problem
             const uint32_t sub = tix / tpa;
             t.b0 = (tix % tpa) << LOGW;
-            t.sub = sub;
             t.in_base = ((uint64_t)sub << (a.L - a.Sp - a.shard_log)) + t.b0;
             t.out_base = t.in_base;
-            t.in_lin = ((uint64_t)sub << (a.L - a.Sp - a.shard_log)) + ((uint64_t)(tix % tpa) << TILE_LOG);   // [sub][tile][row][column]
         } else {
             // lines: k_0 = k0_0 + l (l < W) with the remaining digits a_rest fixed
             const uint32_t g0 = 1u << (a.d0_log - LOGW);   // groups of W adjacent k_0
@@ -274,8 +258,6 @@ template <int LOGR, int LOGW, int KIND, int CAP> struct NttPass {
                 shift_out += a.mid_log[d];
             }
             t.b0 = k0_0;
-            t.sub = a_rest;
-            t.in_lin = (uint64_t)tix << TILE_LOG;          // [a_rest][k_0 / W][k_0 % W][r]
             // line l sits at ((k0_0 + l) * A/R_0 + a_rest) * R: base for l = 0, step (A/R_0)*R
             t.in_base = (((uint64_t)k0_0 << arest_log) + a_rest) << LOGR;
             t.out_base = ((uint64_t)rev << a.d0_log) + k0_0;
@@ -323,15 +305,9 @@ template <int LOGR, int LOGW, int KIND, int CAP> struct NttPass {
                 }
             }
         } else {
-            if (a.in_tm) {      // the tile is one contiguous block, rows of W: row j0 + i * R/16, column w is element tid + i * NT
-                const uint32_t *in = a.in + (uint64_t)batch * a.in_stride + t.in_lin;
+            const uint32_t *in = a.in + (uint64_t)batch * a.in_stride + t.in_base;
 #pragma unroll
-                for (int i = 0; i < V; i++) v[i] = ld32(in, tid + (uint32_t)(i * NT));
-            } else {
-                const uint32_t *in = a.in + (uint64_t)batch * a.in_stride + t.in_base;
-#pragma unroll
-                for (int i = 0; i < V; i++) v[i] = ld32(in, o0 + ((uint32_t)(i * (NT >> LOGW)) << ablog));
-            }
+            for (int i = 0; i < V; i++) v[i] = ld32(in, o0 + ((uint32_t)(i * (NT >> LOGW)) << ablog));
             if (TWIN && (a.flags & NTT_TW_IN)) {
                 // the previous pass's w_m'^(k b'), m' = 2^(L - Sp + prev_logr): k = its output digit = the low
                 // prev_logr bits of this tile's sub-problem index, b' = (row << blog) + column; along a
@@ -371,13 +347,13 @@ template <int LOGR, int LOGW, int KIND, int CAP> struct NttPass {
     // ---- last pass: rows are contiguous in HBM; load coalesced along the row, transpose via LDS.
     // Two phases (global -> registers, registers -> LDS): all 16 loads are in flight together.
     static SMI_HD void load_rows(const PassArgs &a, const TileId &t, uint32_t batch, uint32_t (&v)[V], uint32_t tid) {
-        const uint32_t *in = a.in + (uint64_t)batch * a.in_stride + (a.in_tm ? t.in_lin : t.in_base);
-        const uint32_t lsh = a.in_tm ? (uint32_t)LOGR : a.Sp - a.d0_log + LOGR;   // log2 of the distance between the tile's lines
+        const uint32_t *in = a.in + (uint64_t)batch * a.in_stride + t.in_base;
+        const uint32_t arest_log = a.Sp - a.d0_log;
 #pragma unroll
         for (int i = 0; i < V; i++) {
             const uint32_t idx = tid + i * NT;
             const uint32_t j = idx & (R - 1), l = idx >> LOGR;
-            v[i] = ld32(in, (l << lsh) + j);
+            v[i] = ld32(in, (l << (arest_log + LOGR)) + j);
         }
     }
     static SMI_HD void rows_to_lds(const uint32_t (&v)[V], uint32_t *tile, uint32_t tid) {
@@ -403,11 +379,11 @@ template <int LOGR, int LOGW, int KIND, int CAP> struct NttPass {
     }
     static SMI_HD void load_rows_direct(const PassArgs &a, const TileId &t, uint32_t batch, uint32_t (&v)[V], uint32_t tid) {
         enum { SUB = LOGR - 4 };
-        const uint32_t *in = a.in + (uint64_t)batch * a.in_stride + (a.in_tm ? t.in_lin : t.in_base);
-        const uint32_t lsh = a.in_tm ? (uint32_t)LOGR : a.Sp - a.d0_log + LOGR;   // log2 of the distance between the tile's lines
+        const uint32_t *in = a.in + (uint64_t)batch * a.in_stride + t.in_base;
+        const uint32_t arest_log = a.Sp - a.d0_log;
         uint32_t pos, line;
         direct_map(tid, pos, line);
-        const uint32_t o0 = (line << lsh) + pos;
+        const uint32_t o0 = (line << (arest_log + LOGR)) + pos;
 #pragma unroll
         for (int i = 0; i < V; i++) v[i] = ld32(in, o0 + ((uint32_t)i << SUB));
     }
@@ -468,31 +444,13 @@ template <int LOGR, int LOGW, int KIND, int CAP> struct NttPass {
         return k0 | (k1 << St::s0);
     }
 
-    // Where a strided pass stores frequency k of inner column w (relative to the column's start): base + (k << klog).
-    // Natural order: the place it was loaded from.  PassArgs::out_tm: the next pass's tile-major order.
-    struct OutMap {
-        uint64_t base;
-        uint32_t klog;
-    };
-    static SMI_HD OutMap out_map(const PassArgs &a, const TileId &t, uint32_t w) {
-        const uint32_t blog = a.L - a.Sp - LOGR - a.shard_log;   // row length in memory
-        if (a.out_tm == 1) {          // rows of the next strided pass: (r' | b'hi | b'lo) -> (b'hi | r' | b'lo)
-            const uint32_t b = t.b0 + w, nb = blog - a.nx_logr;
-            const uint32_t r = b >> nb, bhi = (b >> a.nx_logw) & ((1u << (nb - a.nx_logw)) - 1u), blo = b & ((1u << a.nx_logw) - 1u);
-            return OutMap{((uint64_t)t.sub << (a.L - a.Sp)) + ((uint64_t)bhi << (a.nx_logr + a.nx_logw)) + (r << a.nx_logw) + blo, blog};
-        }
-        if (a.out_tm == 2)            // [k_0 = sub][k_1 = k][r] -> [k_1][k_0][r]
-            return OutMap{((uint64_t)t.sub << blog) + t.b0 + w, a.Sp + blog};
-        return OutMap{t.out_base + w, blog};
-    }
-
     // Last in-tile step (radix RL, no step twiddles) fused with the store: outputs leave from
     // registers.  A butterfly's outputs are frequencies k = kbase + kk*(R/RL), kk < RL: an
     // arithmetic progression, so inter-pass twiddles / output scales are running products.
     static SMI_HD void last_step_store(const PassArgs &a, const TileId &t, uint32_t batch, const uint32_t *tile, const Tw2 *tw,
                                        uint32_t tid) {
         enum { NB = (TILE / RL) / NT, KSTEP_LOG = LOGR - SL };
-        uint32_t *out = a.out + (uint64_t)batch * a.out_stride + (LAST ? t.out_base : 0);
+        uint32_t *out = a.out + (uint64_t)batch * a.out_stride + t.out_base;
         const uint32_t mlog = a.L - a.Sp, p = a.F.p;
         // Butterfly bi of a thread has kbase = kbase_0 + bi * RL (its block index advances by R/16,
         // i.e. k_0 by RL), so the per-butterfly bases are running products as well: three table
@@ -527,10 +485,8 @@ template <int LOGR, int LOGW, int KIND, int CAP> struct NttPass {
             dft_regs<SL, CAP>(x, m, tw, LOGR - SL, a.F);   // outputs < CAP*p: fine for any multiply below
             const uint32_t kbase = blk_to_k(blk);
             if constexpr (!LAST) {
-                const OutMap om = out_map(a, t, w);
-                uint32_t *out = a.out + (uint64_t)batch * a.out_stride + om.base;
-                const uint32_t blog = om.klog;                     // log2 of the frequency index's stride in memory
-                const uint32_t o0 = kbase << blog;
+                const uint32_t blog = mlog - LOGR - a.shard_log;   // row length in memory
+                const uint32_t o0 = (kbase << blog) + w;
                 {
                     // inter-pass twiddles w_m^(k*b) = g^k, g = w_m^b: running products over kk (and over
                     // the thread's butterflies, see above).  A per-pass table of (w, Shoup quotient)
@@ -639,10 +595,8 @@ template <int LOGR, int LOGW, int KIND, int CAP> struct NttPass {
     static SMI_HD void last_step_store_mul(const PassArgs &a, const TileId &t, uint32_t batch, const uint32_t *tile, const Tw2 *tw,
                                            uint32_t tid, const uint32_t (&mw)[V], const uint32_t (&mq)[MQ ? V : 1]) {
         enum { NB = (TILE / RL) / NT, KSTEP_LOG = LOGR - SL };
-        // NB > 1 steps the block index by NT / W, never the column: w and with it the output map are per thread
-        const OutMap om = LAST ? OutMap{t.out_base + (tid & (W - 1)), a.Sp} : out_map(a, t, tid & (W - 1));
-        uint32_t *out = a.out + (uint64_t)batch * a.out_stride + om.base;
-        const uint32_t olog = om.klog;   // log2 of the frequency index's stride in memory
+        uint32_t *out = a.out + (uint64_t)batch * a.out_stride + t.out_base;
+        const uint32_t olog = LAST ? a.Sp : a.L - a.Sp - LOGR - a.shard_log;   // log2 of the frequency index's stride in memory
 #pragma unroll
         for (int bi = 0; bi < NB; bi++) {
             const uint32_t u = tid + bi * NT;
@@ -654,7 +608,7 @@ template <int LOGR, int LOGW, int KIND, int CAP> struct NttPass {
 #pragma unroll
             for (int q = 0; q < RL; q++) m[q] = 2;
             dft_regs<SL, CAP>(x, m, tw, LOGR - SL, a.F);
-            const uint32_t o0 = blk_to_k(blk) << olog;
+            const uint32_t o0 = (blk_to_k(blk) << olog) + w;
 #pragma unroll
             for (int kk = 0; kk < RL; kk++)
                 if constexpr (MQ) st32(out, o0 + ((uint32_t)kk << (KSTEP_LOG + olog)), mont_mul_c(x[brev<SL>(kk)], mw[bi * RL + kk], mq[bi * RL + kk], a.F));

@@ -8,10 +8,6 @@ struct NttRequest {
     const uint32_t *in;
     uint32_t *out;
     uint32_t *scratch;   // batch * 2^L elements, required whenever the plan has passes (ntt_make_plan(L, batch).np > 0)
-    uint32_t *scratch2;  // optional second inter-pass buffer of the same size: three-pass plans can then keep their intermediates in
-                         // the consuming pass's tile-major order (PassArgs::in_tm / out_tm, ntt_core.h); nullptr = natural order, in place
-    int tile_major;      // with scratch2: 1 = both intermediates tile-major, 2 = only the one between passes 0 and 1, 3 = only the one
-                         // between passes 1 and 2; 0 = natural order
     uint32_t L;
     uint32_t n_in;       // <= 2^L; inputs beyond it read as zero
     uint32_t batch;
@@ -49,22 +45,14 @@ template <class Launcher> inline bool ntt_run(Launcher &ln, const NttRequest &rq
     uint32_t consumed = 0;
     const uint64_t wgs1 = pl.np >= 3 ? (n >> (pl.logr[1] + pl.logw[1])) * ((rq.batch + SMI_COLS_PER_WG - 1) / SMI_COLS_PER_WG) : 0;
     const bool defer = pl.np >= 3 && (rq.defer_tw == 1 || (rq.defer_tw == 2 && rq.batch > 1 && wgs1 >= SMI_COLS_MIN_WGS));
-    // tile-major intermediates: pass 0 -> scratch (pass 1's order), pass 1 -> scratch2 (the last pass's order), pass 2 -> out
-    const bool tm = pl.np == 3 && rq.scratch2 != nullptr && rq.tile_major != 0;
-    const bool tm1 = tm && rq.tile_major != 3, tm2 = tm && rq.tile_major != 2;
     for (int p = 0; p < pl.np; p++) {
         const bool first = p == 0, last = p == pl.np - 1;
         PassArgs a;
         memset(&a, 0, sizeof a);
-        a.in = first ? rq.in : (tm && p == 2 ? rq.scratch2 : rq.scratch);
+        a.in = first ? rq.in : rq.scratch;
         a.in_stride = first ? rq.in_stride : n;
-        a.out = last ? rq.out : (tm && p == 1 ? rq.scratch2 : rq.scratch);
+        a.out = last ? rq.out : rq.scratch;
         a.out_stride = last ? rq.out_stride : n;
-        if (tm) {
-            a.in_tm = (p == 1 && tm1) || (p == 2 && tm2);
-            a.out_tm = p == 0 && tm1 ? 1u : p == 1 && tm2 ? 2u : 0u;
-            if (p == 0) { a.nx_logr = (uint32_t)pl.logr[1]; a.nx_logw = (uint32_t)pl.logw[1]; }
-        }
         a.F = rq.F; a.T = rq.T; a.S = rq.S;
         a.L = rq.L; a.Sp = consumed; a.n_in = rq.n_in;
         a.flags = (first ? NTT_FIRST : 0) | (first && rq.pre_scale ? NTT_PRE_SCALE : 0) |

@@ -251,44 +251,6 @@ def test_emulated_ntt_deferred_first_twiddle(emu, oracle):
         emu.emu_set_share_cols(1)
 
 
-@pytest.mark.parametrize("tile_major", [0, 1, 2, 3])
-@pytest.mark.parametrize("L,plan", [(18, "6.6,6.6,6.6"), (20, "7.5,7.5,6.6"), (21, None), (21, "9.4,6.6,6.6"), (21, "8.5,7.6,6.6")])
-def test_emulated_ntt_tile_major_intermediates(emu, oracle, L, plan, tile_major):
-    """Three-pass plans with the inter-pass buffers in the consuming pass's tile-major order (PassArgs::in_tm / out_tm,
-    csrc/ntt_core.h: pass 0 stores rows as (b'hi | r' | b'lo), pass 1 stores [k_1][k_0][r], every tile of passes 1 and 2 is
-    one contiguous block; modes 2 and 3: only the first / only the second intermediate) and in natural order (in place,
-    the default): same results either way -- forward zero-padded
-    with a coset offset, inverse with its output scale, one column and three (column-sharing kernels, deferred
-    twiddles), last pass direct and through LDS."""
-    o = oracle
-    n = 1 << L
-    w = o.ff_prim_nth_root_g(n, P2, G2)
-    if plan:
-        os.environ[f"SMI_NTT_PLAN_{L}"] = plan
-    emu.emu_set_tile_major(tile_major)
-    try:
-        a = o.splitmix64(40 + L, n) % np.uint64(P2)
-        for direct in (1, 0):
-            emu.emu_set_last_direct(direct)
-            assert np.array_equal(_ntt(emu, P2, G2, a[:n // 8], L, n // 8, 0, 5), o.fast_coset_ntt(a[:n // 8], n, w, 5, P2))
-            assert np.array_equal(_ntt(emu, P2, G2, a, L, n, 1, 3, post=7), np.array(o.poly_scale(o.fast_intt(a, w, 3, P2), 7, P2), dtype=np.uint64))
-        if L <= 20:
-            cols = np.concatenate([a, np.full(n, P2 - 1, dtype=np.uint64), o.splitmix64(9, n) % np.uint64(P2)])
-            for share, defer in ((2, 1), (1, 2), (2, 0)):
-                emu.emu_set_share_cols(share)
-                emu.emu_set_defer_tw(defer)
-                got = _ntt(emu, P2, G2, cols, L, n // 4, 0, 1, batch=3, in_stride=n).reshape(3, n)
-                for c in range(3):
-                    assert np.array_equal(got[c], o.fast_coset_ntt(cols[c * n:c * n + n // 4], n, w, 1, P2)), (c, share, defer)
-    finally:
-        emu.emu_set_tile_major(0)
-        emu.emu_set_last_direct(1)
-        emu.emu_set_share_cols(1)
-        emu.emu_set_defer_tw(2)
-        if plan:
-            del os.environ[f"SMI_NTT_PLAN_{L}"]
-
-
 @pytest.mark.parametrize("direct", [1, 0])
 @pytest.mark.parametrize("p,g", [(P, G), (P2, G2)])
 @pytest.mark.parametrize("L", [13, 14, 15, 16, 17, 18, 19, 20])
