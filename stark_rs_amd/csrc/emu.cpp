@@ -426,6 +426,67 @@ extern "C" void emu_node_hash_quad(const uint8_t *pairs, size_t n, uint8_t *out)
     }
 }
 
+// ---- one hash over a row of sixteen lanes (hash_hex.h): the device code itself, with `word` = sixteen lanes stepped in
+// lockstep and the DPP row moves as permutations of those sixteen values
+struct H16 {
+    uint32_t v[16];
+    H16() { for (int i = 0; i < 16; i++) v[i] = 0; }
+    H16(uint32_t x) { for (int i = 0; i < 16; i++) v[i] = x; }
+};
+#define H16_BIN(op)                                                \
+    inline H16 operator op(const H16 &a, const H16 &b) {           \
+        H16 r;                                                     \
+        for (int i = 0; i < 16; i++) r.v[i] = a.v[i] op b.v[i];    \
+        return r;                                                  \
+    }
+H16_BIN(+) H16_BIN(^) H16_BIN(&) H16_BIN(|) H16_BIN(*)
+#undef H16_BIN
+inline H16 operator<<(const H16 &a, int sh) { H16 r; for (int i = 0; i < 16; i++) r.v[i] = a.v[i] << sh; return r; }
+inline H16 operator>>(const H16 &a, int sh) { H16 r; for (int i = 0; i < 16; i++) r.v[i] = a.v[i] >> sh; return r; }
+namespace hashc {
+#define H16_MAP3(name)                                                         \
+    inline H16 name(const H16 &a, const H16 &b, const H16 &c) {                \
+        H16 r;                                                                 \
+        for (int i = 0; i < 16; i++) r.v[i] = name(a.v[i], b.v[i], c.v[i]);    \
+        return r;                                                              \
+    }
+H16_MAP3(pk_mad_u16) H16_MAP3(bfi32) H16_MAP3(xor3)
+#undef H16_MAP3
+inline H16 funnel16(const H16 &hi, const H16 &lo) { H16 r; for (int i = 0; i < 16; i++) r.v[i] = funnel16(hi.v[i], lo.v[i]); return r; }
+}  // namespace hashc
+#define SMI_HEX_EMU
+namespace hashx {
+#define SMI_XD inline
+typedef H16 word;
+template <int N> inline H16 rot(const H16 &x) { H16 r; for (int i = 0; i < 16; i++) r.v[i] = x.v[(i - N) & 15]; return r; }
+template <int N> inline H16 shr(const H16 &x) { H16 r; for (int i = 0; i < 16; i++) r.v[i] = i >= N ? x.v[i - N] : 0u; return r; }
+template <int P0, int P1, int P2, int P3> inline H16 quad(const H16 &x) {
+    const int P[4] = {P0, P1, P2, P3};
+    H16 r;
+    for (int i = 0; i < 16; i++) r.v[i] = x.v[(i & ~3) | P[i & 3]];
+    return r;
+}
+inline H16 lane_in_row(uint32_t) { H16 r; for (int i = 0; i < 16; i++) r.v[i] = (uint32_t)i; return r; }
+inline H16 mask_range(const H16 &w, uint32_t lo, uint32_t hi) { H16 r; for (int i = 0; i < 16; i++) r.v[i] = w.v[i] >= lo && w.v[i] < hi ? ~0u : 0u; return r; }
+inline H16 table16(const H16 &w, const uint32_t (&t)[16]) { H16 r; for (int i = 0; i < 16; i++) r.v[i] = t[w.v[i] & 15]; return r; }
+inline H16 perm8v(const H16 &hi, const H16 &lo, const H16 &sel) { H16 r; for (int i = 0; i < 16; i++) r.v[i] = hashc::perm8(hi.v[i], lo.v[i], sel.v[i]); return r; }
+inline H16 lshl_or(const H16 &a, int sh, const H16 &b) { return (a << sh) | b; }
+inline H16 lshl_add(const H16 &a, int sh, const H16 &b) { return (a << sh) + b; }
+}  // namespace hashx
+#include "hash_hex.h"
+extern "C" void emu_node_hash_hex(const uint8_t *pairs, size_t n, uint8_t *out) {
+    const hashx::Lane L = hashx::make_lane(0);
+    for (size_t i = 0; i < n; i++) {
+        uint32_t l[8], r[8];
+        memcpy(l, pairs + 64 * i, 32);
+        memcpy(r, pairs + 64 * i + 32, 32);
+        H16 llo, lhi, rlo, rhi;   // what each lane loads: natural words w >> 2 and 4 + (w >> 2) of either child
+        for (int w = 0; w < 16; w++) { llo.v[w] = l[w >> 2]; lhi.v[w] = l[4 + (w >> 2)]; rlo.v[w] = r[w >> 2]; rhi.v[w] = r[4 + (w >> 2)]; }
+        const H16 x = hashx::node_hash(hashx::message(llo, lhi, L), hashx::message(rlo, rhi, L), L);
+        for (int w = 0; w < 16; w++) { out[32 * i + w] = (uint8_t)x.v[w]; out[32 * i + 16 + w] = (uint8_t)(x.v[w] >> 16); }
+    }
+}
+
 // rows of W residues, row-major in `v`: pairs through row_hash2 when W <= 4, the rest through row_hash
 extern "C" void emu_row_hash(const uint32_t *v, size_t n_rows, int W, uint8_t *out) {
     size_t i = 0;

@@ -39,8 +39,11 @@ struct FsState {
     uint32_t s[16];
 };
 
-__global__ void fs_init_kernel(FsState *fs) {
-    if (threadIdx.x || blockIdx.x) return;
+// (ride_*: a few bytes of the caller's -- the column roots of a prove -- placed behind the proof, to come back with its copy)
+__global__ void fs_init_kernel(FsState *fs, const uint8_t *ride_src = nullptr, uint8_t *ride_dst = nullptr, size_t ride_n = 0) {
+    if (blockIdx.x) return;
+    for (size_t i = threadIdx.x; i < ride_n; i += blockDim.x) ride_dst[i] = ride_src[i];
+    if (threadIdx.x) return;
     hashc::State st;
     hashc::init(st);
     for (int i = 0; i < 16; i++) fs->s[i] = st.s[i];
@@ -184,8 +187,23 @@ __device__ void write_path(uint8_t *dst, const uint8_t *nodes, uint64_t n, uint3
         len >>= 1;
     }
 }
+// The layer table travels as a kernel argument while it fits (SMI_QUERY_TAB_MAX layers: codewords of up to 2^40
+// elements): a host-to-device copy between the index sampling and this launch would sit on the critical path of
+// the prove with the runtime's gaps around it (profiles/r03_b_prove_timeline.txt).
+#define SMI_QUERY_TAB_MAX 40
+struct LayerTable {
+    LayerInfo l[SMI_QUERY_TAB_MAX];
+};
+__device__ __forceinline__ void query_one(const LayerInfo &L, const uint64_t *top, uint8_t *proof);
 __global__ void query_kernel(const LayerInfo *layers, const uint64_t *top, uint32_t t, uint8_t *proof) {
     const LayerInfo L = layers[blockIdx.y];
+    query_one(L, top, proof);
+}
+__global__ void query_tab_kernel(const LayerTable tab, const uint64_t *top, uint32_t t, uint8_t *proof) {
+    const LayerInfo L = tab.l[blockIdx.y];
+    query_one(L, top, proof);
+}
+__device__ __forceinline__ void query_one(const LayerInfo &L, const uint64_t *top, uint8_t *proof) {
     const uint32_t s = blockIdx.x, lane = threadIdx.x;
     const uint64_t half = L.len / 2;
     const uint64_t c = top[s] % half;   // indices folded layer by layer: (x % a) % b == x % b for b | a
@@ -422,16 +440,27 @@ int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, si
 
     const MiscLayout ml = misc_layout(R, t);
     if (!(run->d_misc = run_alloc(run, ml.total))) return bail(smi_fail(ctx, SMI_ERR_OOM, "alloc misc"));
-    if (!(run->d_proof = (uint8_t *)run_alloc(run, proof_len))) return bail(smi_fail(ctx, SMI_ERR_OOM, "alloc proof"));
+    // The challenges, the sampled indices and the caller's ride-along bytes live behind the proof in ONE device buffer, so
+    // that everything the host needs comes back in a single device-to-host copy: four copies cost 17 + 5 + 4 + 4 us of blit
+    // kernels and 86 us of runtime gaps between them at the end of every prove (profiles/r03_b_prove_timeline.txt).
+    const size_t off_al = (proof_len + 7) & ~(size_t)7, off_top = off_al + 8 * R, off_ride = off_top + 8 * (t + 1);
+    const void *ride_src = ctx->ride_src;
+    const size_t ride_bytes = ride_src ? ctx->ride_bytes : 0;
+    void *ride_dst = ctx->ride_dst;
+    ctx->ride_src = nullptr;
+    ctx->ride_bytes = 0;
+    ctx->ride_dst = nullptr;
+    const size_t back_len = off_ride + ride_bytes;
+    if (!(run->d_proof = (uint8_t *)run_alloc(run, back_len))) return bail(smi_fail(ctx, SMI_ERR_OOM, "alloc proof"));
     uint8_t *misc = (uint8_t *)run->d_misc;
     FsState *d_fs = (FsState *)(misc + ml.fs);
-    uint64_t *d_alphas = (uint64_t *)(misc + ml.alphas);
+    uint64_t *d_alphas = (uint64_t *)(run->d_proof + off_al);
     uint64_t *d_seed_ch = (uint64_t *)(misc + ml.seed_ch);
-    uint64_t *d_top = (uint64_t *)(misc + ml.top);
+    uint64_t *d_top = (uint64_t *)(run->d_proof + off_top);
     uint64_t *d_reduced = (uint64_t *)(misc + ml.reduced);
     LayerInfo *d_layers = (LayerInfo *)(misc + ml.layers);
 
-    fs_init_kernel<<<1, 64, 0, ctx->stream>>>(d_fs);
+    fs_init_kernel<<<1, 64, 0, ctx->stream>>>(d_fs, (const uint8_t *)ride_src, run->d_proof + off_ride, ride_bytes);
 
     uint32_t omega = (uint32_t)cfg->omega, offset = (uint32_t)cfg->offset;
     const uint32_t *cur = d_codeword;
@@ -444,6 +473,7 @@ int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, si
     // the per-round path spreads a tree's 64-leaf chunks over several CUs).  SMI_FRI_TAIL=<len> overrides
     // (0: never).
     const uint64_t tail_len = fri_tail_len();
+    static const bool fold_in_tail = !(getenv("SMI_MERKLE_FUSE") && atoi(getenv("SMI_MERKLE_FUSE")) == 0);
     // The leaves of a round's tree can be computed by the launch that hashes them (LeafSrc, internal.h): the initial
     // codeword as the caller's weighted column sum (round0_src), every later one as the fold of the round before --
     // wherever the tree starts with the four-leaves-per-lane kernel (merkle_fuses_leaf_source).  The codeword buffer is
@@ -467,6 +497,13 @@ int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, si
             ta.fs_words = d_fs->s;
             ta.F = ctx->fs.F;
             ta.inv2_m = (uint32_t)(((uint64_t)h_inv(ctx, 2) << 32) % p);
+            if (have_pending) {   // the fold into this codeword runs at the head of the tail launch
+                ta.pre_lo = pending.lo;
+                ta.pre_hi = pending.hi;
+                ta.pre_alpha = pending.alpha;
+                ta.pre_S = pending.S;
+                have_pending = false;
+            }
             for (uint64_t k = r; k < R; k++) {
                 FriTailRound &tr = ta.r[k - r];
                 const bool last = k == R - 1;
@@ -521,8 +558,10 @@ int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, si
         // (the computed-leaf kernel reads and writes four elements at a time: 16-byte aligned buffers only -- the library's own
         // are, a caller's initial codeword need not be)
         const bool aligned16 = (((uintptr_t)cur | (uintptr_t)next) & 15u) == 0;
-        if (merkle_fuses_leaf_source(next_len) && !next_is_tail && aligned16) {
-            // no fold launch: the next round's leaf kernel folds (same checks and tables as launch_fold_shard)
+        if ((merkle_fuses_leaf_source(next_len) && !next_is_tail && aligned16) || (merkle_chunks_fold(next_len) && !next_is_tail) ||
+            (next_is_tail && fold_in_tail)) {
+            // no fold launch: the next round's leaf kernel (the four-leaves-per-lane kernel, the chunk kernel or the fused
+            // tail, whichever that round starts with) folds (same checks and tables as launch_fold_shard)
             if (offset == 0 || omega == 0) {
                 if (!run->arena) (void)hipFree(next);
                 return bail(smi_fail(ctx, SMI_ERR_DIV_BY_ZERO, "no division by zero"));   // src/ff.rs:182
@@ -563,28 +602,25 @@ int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, si
                 layers[i].nodes = run->trees[i];
                 layers[i].nodes_next = run->trees[i + 1];
             }
-            if (hipMemcpyAsync(d_layers, layers.data(), sizeof(LayerInfo) * (R - 1), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
-                return bail(smi_fail(ctx, SMI_ERR_HIP, "hipMemcpyAsync layers"));
-            query_kernel<<<dim3((uint32_t)t, (uint32_t)(R - 1)), 64, 0, ctx->stream>>>(d_layers, d_top, (uint32_t)t, run->d_proof);
+            if (R - 1 <= SMI_QUERY_TAB_MAX) {
+                LayerTable tab;
+                memset(&tab, 0, sizeof tab);
+                memcpy(tab.l, layers.data(), sizeof(LayerInfo) * (R - 1));
+                query_tab_kernel<<<dim3((uint32_t)t, (uint32_t)(R - 1)), 64, 0, ctx->stream>>>(tab, d_top, (uint32_t)t, run->d_proof);
+            } else {
+                if (hipMemcpyAsync(d_layers, layers.data(), sizeof(LayerInfo) * (R - 1), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+                    return bail(smi_fail(ctx, SMI_ERR_HIP, "hipMemcpyAsync layers"));
+                query_kernel<<<dim3((uint32_t)t, (uint32_t)(R - 1)), 64, 0, ctx->stream>>>(d_layers, d_top, (uint32_t)t, run->d_proof);
+            }
         }
     }
     if (hipGetLastError() != hipSuccess) return bail(smi_fail(ctx, SMI_ERR_HIP, "fri kernel launch"));
 
-    // one synchronising copy-back, through the context's pinned landing buffer: proof | challenges | indices
-    const size_t off_al = (proof_len + 7) & ~(size_t)7, off_top = off_al + 8 * R, off_ride = off_top + 8 * (t + 1);
-    const void *ride_src = ctx->ride_src;
-    const size_t ride_bytes = ride_src ? ctx->ride_bytes : 0;
-    void *ride_dst = ctx->ride_dst;
-    ctx->ride_src = nullptr;
-    ctx->ride_bytes = 0;
-    ctx->ride_dst = nullptr;
+    // one synchronising copy-back, through the context's pinned landing buffer: proof | challenges | indices | ride-along
     uint8_t *land = nullptr;
-    if ((rc = ctx_pin_out(ctx, off_ride + ride_bytes, &land)) != SMI_OK) return bail(rc);
-    if (ride_bytes) (void)hipMemcpyAsync(land + off_ride, ride_src, ride_bytes, hipMemcpyDeviceToHost, ctx->stream);
-    if (hipMemcpyAsync(land, run->d_proof, proof_len, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+    if ((rc = ctx_pin_out(ctx, back_len, &land)) != SMI_OK) return bail(rc);
+    if (hipMemcpyAsync(land, run->d_proof, back_len, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
         return bail(smi_fail(ctx, SMI_ERR_HIP, "copy proof"));
-    if (R > 1) (void)hipMemcpyAsync(land + off_al, d_alphas, 8 * (R - 1), hipMemcpyDeviceToHost, ctx->stream);
-    if (do_query && t) (void)hipMemcpyAsync(land + off_top, d_top, 8 * t, hipMemcpyDeviceToHost, ctx->stream);
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return bail(smi_hip_fail(ctx, e, "fri sync"));
     std::vector<uint8_t> proof(land, land + proof_len);

@@ -15,6 +15,7 @@
 #include "fri_core.h"
 #include "hash_core.h"
 #include "hash_quad.h"
+#include "hash_hex.h"
 #include "internal.h"
 
 #define SMI_HASH_THREADS 256
@@ -196,6 +197,11 @@ __global__ __launch_bounds__(SMI_HASH_THREADS) void merkle_sub_kernel(const uint
 #ifndef SMI_TOP_QUAD
 #define SMI_TOP_QUAD 1     // levels with at most SMI_TOP_THREADS / 4 nodes hash over quads of lanes
 #endif
+#ifndef SMI_TOP_HEX
+#define SMI_TOP_HEX 16     // levels with at most this many nodes hash over rows of sixteen lanes (hash_hex.h); 0: never.
+#endif                     // 16 nodes = 256 lanes = one wave per SIMD: a level of a 1024-lane workgroup takes 1.0 us that way and
+                           // 1.45 over quads; with 32 nodes (two waves per SIMD) both take 1.5, with 64 the rows lose, 2.5 to 1.5
+                           // (tools/quad_hash_test.hip, profiles/r03_y_tophash_ubench.log)
 #define SMI_TOP_MAX 2048
 #define SMI_TOP_THREADS (SMI_TOP_MAX / 2)
 // Optional epilogue of the launch that produces a tree's root: the Fiat-Shamir round of Fri::commit
@@ -208,14 +214,22 @@ struct TopHook {
 // One workgroup: leaf digests (FROM_ELEMS) or the digests of level lvl_in for positions [first, first + chunk),
 // then every level above them down to the chunk's root; all of it written to `nodes`.  Returns the
 // slot of each word row of buf ([8][SMI_TOP_MAX]) that holds the root.
-template <bool FROM_ELEMS>
+// FOLD (with FROM_ELEMS): element first + i is not read but computed -- Fri::fold_codeword of the round before (LeafSrc,
+// LEAF_FOLD: fri_core.h fold_element, what the stand-alone fri_fold_kernel runs) -- and stored to src.cw_out on the way.
+template <bool FROM_ELEMS, bool FOLD = false>
 __device__ __forceinline__ uint32_t top_chunk(const uint32_t *__restrict__ elems, uint4 *nodes, size_t n, uint32_t lvl_in, uint32_t chunk,
-                                              size_t first, uint32_t row_cols, size_t row_stride, uint32_t *buf) {
+                                              size_t first, uint32_t row_cols, size_t row_stride, uint32_t *buf, const LeafSrc *src = nullptr) {
     const uint32_t tid = threadIdx.x;
     uint32_t d[8];
+    uint32_t ah_m = 0;
+    if constexpr (FOLD) ah_m = fold_alpha_half(*src->alpha, src->inv2_m, src->F);
     for (uint32_t i = tid; i < chunk; i += SMI_TOP_THREADS) {
         if (FROM_ELEMS) {
-            if (row_cols) {
+            if constexpr (FOLD) {
+                const uint32_t v = fold_element(src->lo[first + i], src->hi[first + i], (uint32_t)(first + i), ah_m, src->inv2_m, src->S, src->F);
+                src->cw_out[first + i] = v;
+                hashc::leaf_hash(v, d);
+            } else if (row_cols) {
                 uint32_t row[4];
                 for (uint32_t c = 0; c < 4; c++) row[c] = c < row_cols ? elems[c * row_stride + first + i] : 0u;
                 hashc::row_hash(row, (int)row_cols, d);
@@ -235,9 +249,31 @@ __device__ __forceinline__ uint32_t top_chunk(const uint32_t *__restrict__ elems
     __syncthreads();
     uint32_t lvl = lvl_in, base = 0;
     const hashq::Lane lane = hashq::make_lane(tid);
+    const hashx::Lane row = hashx::make_lane(tid);
     for (uint32_t cnt = chunk; cnt > 1; cnt >>= 1) {   // cnt, lvl are workgroup-uniform
         const uint32_t half = cnt >> 1;
         lvl++;
+        if (SMI_TOP_HEX && half <= SMI_TOP_HEX && 16 * half <= SMI_TOP_THREADS) {
+            // very few nodes: one hash per row of sixteen lanes, one state word per lane (hash_hex.h): 0.91 us per node hash
+            // in a wave of its own where the quad form takes 1.42.  Lane w reads bytes w and 16 + w of each child (natural words
+            // w >> 2 and 4 + (w >> 2)) and writes those two bytes of the digest.  Slots alternate as in the quad levels.
+            const uint32_t node = tid >> 4, w = tid & 15u, j = w >> 2;
+            if (node < half) {
+                const uint32_t *src = buf + base + 2 * node;
+                const uint32_t ml = hashx::message(src[j * SMI_TOP_MAX], src[(4 + j) * SMI_TOP_MAX], row);
+                const uint32_t mr = hashx::message(src[j * SMI_TOP_MAX + 1], src[(4 + j) * SMI_TOP_MAX + 1], row);
+                const uint32_t x = hashx::node_hash(ml, mr, row);
+                uint8_t *dst = (uint8_t *)(nodes + 2 * (level_offset(n, lvl) + (first >> (lvl - lvl_in)) + node));
+                dst[w] = (uint8_t)x;
+                dst[16 + w] = (uint8_t)(x >> 16);
+                uint8_t *nb = (uint8_t *)(buf + (base ^ (SMI_TOP_MAX / 2)) + node);
+                nb[4 * (j * SMI_TOP_MAX) + (w & 3u)] = (uint8_t)x;
+                nb[4 * ((4 + j) * SMI_TOP_MAX) + (w & 3u)] = (uint8_t)(x >> 16);
+            }
+            base ^= SMI_TOP_MAX / 2;
+            __syncthreads();
+            continue;
+        }
         if (SMI_TOP_QUAD && 4 * half <= SMI_TOP_THREADS) {
             // few nodes: a level is one node-hash latency, so each hash is spread over a quad of lanes
             // (hash_quad.h); lane q of the quad ends up with digest words q and q+4
@@ -284,6 +320,21 @@ __device__ __forceinline__ uint32_t top_chunk(const uint32_t *__restrict__ elems
     return base;
 }
 
+// the Fiat-Shamir round of the root by the launch that produced it (TopHook)
+__device__ __forceinline__ void top_finish(const TopHook &hook, const uint32_t *buf, uint32_t base) {
+    if (hook.fs_words && threadIdx.x == 0 && gridDim.x == 1 && blockIdx.y == 0) {   // the root sits in slot `base` of every word row
+        uint32_t m[8];
+#pragma unroll
+        for (int w = 0; w < 8; w++) m[w] = buf[w * SMI_TOP_MAX + base];
+        hashc::fs_absorb_root(hook.fs_words, m, hook.proof_slot, hook.alpha_out);
+    }
+}
+// one tree whose leaves are the fold of the round before (LeafSrc, LEAF_FOLD), chunk by chunk
+__global__ __launch_bounds__(SMI_TOP_THREADS) void merkle_top_fold_kernel(uint4 *nodes, size_t n, uint32_t chunk, TopHook hook, const LeafSrc src) {
+    __shared__ uint32_t buf[8 * SMI_TOP_MAX];
+    const uint32_t base = top_chunk<true, true>(src.cw_out, nodes, n, 0, chunk, (size_t)blockIdx.x * chunk, 0, 0, buf, &src);
+    top_finish(hook, buf, base);
+}
 template <bool FROM_ELEMS>
 __global__ __launch_bounds__(SMI_TOP_THREADS) void merkle_top_kernel(const uint32_t *__restrict__ elems, uint4 *nodes, size_t n,
                                                                       uint32_t lvl_in, uint32_t chunk, size_t elem_stride,
@@ -293,12 +344,7 @@ __global__ __launch_bounds__(SMI_TOP_THREADS) void merkle_top_kernel(const uint3
     elems += (size_t)blockIdx.y * elem_stride;
     nodes += (size_t)blockIdx.y * node_stride;
     const uint32_t base = top_chunk<FROM_ELEMS>(elems, nodes, n, lvl_in, chunk, (size_t)blockIdx.x * chunk, row_cols, row_stride, buf);
-    if (hook.fs_words && threadIdx.x == 0 && gridDim.x == 1 && blockIdx.y == 0) {   // the root sits in slot `base` of every word row
-        uint32_t m[8];
-#pragma unroll
-        for (int w = 0; w < 8; w++) m[w] = buf[w * SMI_TOP_MAX + base];
-        hashc::fs_absorb_root(hook.fs_words, m, hook.proof_slot, hook.alpha_out);
-    }
+    top_finish(hook, buf, base);
 }
 
 // The tail of Fri::commit (reference src/fri.rs:116-148) in ONE launch: once a codeword has at most
@@ -309,6 +355,13 @@ __global__ __launch_bounds__(SMI_TOP_THREADS) void merkle_top_kernel(const uint3
 __global__ __launch_bounds__(SMI_TOP_THREADS) void fri_tail_kernel(const FriTailArgs a) {
     __shared__ uint32_t buf[8 * SMI_TOP_MAX];
     const uint32_t tid = threadIdx.x;
+    if (a.pre_lo) {   // the fold into the first codeword of the tail (otherwise a launch of its own before this one)
+        const uint32_t ah_m = fold_alpha_half(*a.pre_alpha, a.inv2_m, a.F);
+        uint32_t *cw0 = const_cast<uint32_t *>(a.r[0].cw);
+        for (uint32_t i = tid; i < a.r[0].len; i += SMI_TOP_THREADS) cw0[i] = fold_element(a.pre_lo[i], a.pre_hi[i], i, ah_m, a.inv2_m, a.pre_S, a.F);
+        __threadfence_block();
+        __syncthreads();
+    }
     for (uint32_t k = 0; k < a.n_rounds; k++) {
         const FriTailRound R = a.r[k];
         const uint32_t base = top_chunk<true>(R.cw, (uint4 *)R.nodes, R.len, 0, R.len, 0, 0, 0, buf);
@@ -527,10 +580,16 @@ bool merkle_fuses_leaf_source(size_t n) {
                             (getenv("SMI_MERKLE_K") && atoi(getenv("SMI_MERKLE_K")) != 2);
     return !off && n >= 8 && (n & (n - 1)) == 0 && n > (size_t)SMI_TOP_MAX * merkle_top_blocks();
 }
+// ... and with at most that many (and at least two) the first launch is the chunk kernel, which can fold as it reads
+bool merkle_chunks_fold(size_t n) {
+    static const bool off = getenv("SMI_MERKLE_FUSE") && atoi(getenv("SMI_MERKLE_FUSE")) == 0;
+    return !off && n >= 2 && (n & (n - 1)) == 0 && n <= (size_t)SMI_TOP_MAX * merkle_top_blocks();
+}
 // one tree whose leaves are computed by the launch that hashes them (src.cw_out receives the codeword)
 int launch_merkle_src_fs(smi_ctx *ctx, const LeafSrc &src, size_t n, uint8_t *d_nodes, uint32_t *fs_words, uint8_t *proof_slot,
                          uint64_t *alpha_out, bool *done) {
-    if (!merkle_fuses_leaf_source(n) || !src.cw_out || (src.kind == LEAF_COMBINE && (!src.n_cols || src.n_cols > SMI_LEAF_COMBINE_MAX)))
+    const bool ok = merkle_fuses_leaf_source(n) || (src.kind == LEAF_FOLD && merkle_chunks_fold(n));
+    if (!ok || !src.cw_out || (src.kind == LEAF_COMBINE && (!src.n_cols || src.n_cols > SMI_LEAF_COMBINE_MAX)))
         return smi_fail(ctx, SMI_ERR_BAD_ARG, "merkle: this tree cannot take a computed leaf source");
     const TopHook hook{fs_words, proof_slot, alpha_out};
     *done = false;
@@ -601,7 +660,10 @@ static int launch_merkle_impl(smi_ctx *ctx, const uint32_t *d_elems, size_t n, u
                 h = *hook;
                 *hook_done = true;
             }
-            if (from_elems)
+            if (from_elems && src) {
+                if (src->kind != LEAF_FOLD || n_trees != 1 || row_cols) return smi_fail(ctx, SMI_ERR_BAD_ARG, "merkle: the chunk kernel computes folded leaves only");
+                merkle_top_fold_kernel<<<grid, SMI_TOP_THREADS, 0, ctx->stream>>>(nodes, n, (uint32_t)chunk, h, *src);
+            } else if (from_elems)
                 merkle_top_kernel<true><<<grid, SMI_TOP_THREADS, 0, ctx->stream>>>(d_elems, nodes, n, 0, (uint32_t)chunk, elem_stride, node_stride, row_cols, row_stride, h);
             else
                 merkle_top_kernel<false><<<grid, SMI_TOP_THREADS, 0, ctx->stream>>>(nullptr, nodes, n, lvl, (uint32_t)chunk, 0, node_stride, 0, 0, h);

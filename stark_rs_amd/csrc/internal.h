@@ -183,6 +183,11 @@ struct FriTailArgs {
     uint32_t *fs_words;
     Fp F;
     uint32_t inv2_m;
+    // optional: the fold that produces r[0].cw (from the halves pre_lo / pre_hi of the round before, with its challenge
+    // and x^-1 table) runs at the head of the launch instead of in a fold launch of its own; pre_lo == nullptr: it does not
+    const uint32_t *pre_lo, *pre_hi;
+    const uint64_t *pre_alpha;
+    ScaleTables pre_S;
 };
 int launch_fri_tail(smi_ctx *ctx, const FriTailArgs &a);
 uint64_t fri_tail_len();   // codewords of at most this many elements finish in the fused tail (SMI_FRI_TAIL, default 512; fri.hip)
@@ -213,6 +218,9 @@ struct LeafSrc {
 };
 // true when a tree of n single-element leaves starts with the thread-per-four-leaves kernel that can take a LeafSrc
 bool merkle_fuses_leaf_source(size_t n);
+// true when a tree of n single-element leaves starts with the chunk kernel, which can take a LEAF_FOLD source (no other
+// kind; no alignment demands: it reads and writes single elements)
+bool merkle_chunks_fold(size_t n);
 int launch_merkle_src_fs(smi_ctx *ctx, const LeafSrc &src, size_t n, uint8_t *d_nodes, uint32_t *fs_words, uint8_t *proof_slot,
                          uint64_t *alpha_out, bool *done);
 

@@ -27,13 +27,14 @@ int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, si
 
 // weights[c] = FiatShamir::challenge after absorbing roots[0..c] (unreduced u64)
 // weights_m (optional): the same weights reduced mod p in Montgomery form, what the fused combination multiplies by
+// the roots are named by a pointer table, or (root_ptrs == nullptr) sit root_stride bytes apart from root0 on
 __global__ void fs_weights_kernel(const uint8_t *const *root_ptrs, uint32_t n, uint64_t *weights, uint32_t *roots_out,
-                                  uint32_t *weights_m = nullptr, Fp F = Fp{0, 0, 0, 0}) {
+                                  uint32_t *weights_m = nullptr, Fp F = Fp{0, 0, 0, 0}, const uint8_t *root0 = nullptr, size_t root_stride = 0) {
     if (threadIdx.x || blockIdx.x) return;
     hashc::State st;
     hashc::init(st);
     for (uint32_t c = 0; c < n; c++) {
-        const uint32_t *root = (const uint32_t *)root_ptrs[c];
+        const uint32_t *root = (const uint32_t *)(root_ptrs ? root_ptrs[c] : root0 + (size_t)c * root_stride);
         uint32_t m[8];
         for (int i = 0; i < 8; i++) roots_out[8 * c + i] = m[i] = root[i];   // gathered: one copy to the host
         hashc::absorb_chunk32(st, m);
@@ -138,8 +139,7 @@ int smi_dev_stark_prove(smi_ctx *ctx, const smi_stark_cfg *cfg, const uint32_t *
     uint32_t *d_cw = (uint32_t *)arena_alloc(ctx, N * 4);
     uint64_t *d_weights = (uint64_t *)arena_alloc(ctx, 8 * W);
     uint32_t *d_weights_m = (uint32_t *)arena_alloc(ctx, 4 * W);
-    const uint8_t **d_rootp = (const uint8_t **)arena_alloc(ctx, sizeof(void *) * W);
-    if (!d_lde || !d_cw || !d_weights || !d_weights_m || !d_rootp) return smi_fail(ctx, SMI_ERR_OOM, "stark_prove: device memory");
+    if (!d_lde || !d_cw || !d_weights || !d_weights_m) return smi_fail(ctx, SMI_ERR_OOM, "stark_prove: device memory");
     std::vector<uint8_t *> trees(W);
     std::vector<const uint8_t *> rootp(W);
     // the W column trees sit back to back (stride 2N digests) so one set of launches builds them all
@@ -161,8 +161,8 @@ int smi_dev_stark_prove(smi_ctx *ctx, const smi_stark_cfg *cfg, const uint32_t *
     if (cfg->row_leaves) {
         fs_row_weights_kernel<<<1, 64, 0, ctx->stream>>>(rootp[0], W, d_weights, d_roots, d_weights_m, ctx->fs.F);
     } else {
-        HIP_TRY(ctx, hipMemcpyAsync(d_rootp, rootp.data(), sizeof(void *) * W, hipMemcpyHostToDevice, ctx->stream));
-        fs_weights_kernel<<<1, 64, 0, ctx->stream>>>(d_rootp, W, d_weights, (uint32_t *)d_roots, d_weights_m, ctx->fs.F);
+        // (no pointer table: a host-to-device copy here would sit between the commit and the first FRI launch)
+        fs_weights_kernel<<<1, 64, 0, ctx->stream>>>(nullptr, W, d_weights, (uint32_t *)d_roots, d_weights_m, ctx->fs.F, rootp[0], tree_stride);
     }
     HIP_TRY(ctx, hipGetLastError());
     // Sum_c weight_c * col_c: by a kernel of its own, or -- when the first FRI tree starts with the four-leaves-per-lane

@@ -104,6 +104,28 @@ def test_emulated_node_hash_over_a_quad_of_lanes(emu, oracle):
         assert bytes(out[i]) == o.hash_combine(bytes(pairs[i, :32]), bytes(pairs[i, 32:])), i
 
 
+def test_emulated_hex_node_hash(emu, oracle):
+    """hash_hex.h -- the node hash of the narrowest Merkle levels, one state word per lane of a row of sixteen (S-box per
+    lane, linear mix over quad_perm moves, ring add as a row scan, absorb recurrence as five rotate-by-seven stages)
+    stepped in lockstep on the CPU: Hash::combine of random, all-zero, all-ones, repeated-byte and single-byte children."""
+    o = oracle
+    rng = np.random.default_rng(10)
+    pairs = rng.integers(0, 256, (400, 64), dtype=np.uint8)
+    pairs[0] = 0
+    pairs[1] = 255
+    pairs[2, :32] = 0
+    pairs[3, 32:] = 255
+    for k in range(4, 20):
+        pairs[k] = (k * 37) & 255
+    for k in range(64):   # one non-zero byte at every position: each step of the absorb recurrence on its own
+        pairs[20 + k] = 0
+        pairs[20 + k, k] = 0x80 | k
+    out = np.zeros((len(pairs), 32), dtype=np.uint8)
+    emu.emu_node_hash_hex(pairs.ctypes.data_as(C.c_void_p), C.c_size_t(len(pairs)), out.ctypes.data_as(C.c_void_p))
+    for i in range(len(pairs)):
+        assert bytes(out[i]) == o.hash_combine(bytes(pairs[i, :32]), bytes(pairs[i, 32:])), i
+
+
 @pytest.mark.parametrize("L,plan", [
     (18, "9.3,9.3"), (18, "9.5,9.4"), (18, "10.4,8.4"), (18, "6.6,6.6,6.6"), (19, "7.6,6.6,6.6"), (20, "10.2,10.2"),
     (20, "10.4,10.3"), (20, "7.5,7.5,6.6"), (20, "8.6,6.6,6.6"), (21, "8.5,7.6,6.6"), (21, "9.4,6.6,6.6"),

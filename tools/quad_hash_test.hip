@@ -1,11 +1,13 @@
-// Development tool: hashq::node_hash (one hash over a quad of lanes) against hashc::node_hash on the
-// device, and the latency of a chain of dependent node hashes in a single wave either way.
+// Development tool: hashq::node_hash (one hash over a quad of lanes) and hashx::node_hash (over a row of sixteen) against
+// hashc::node_hash on the device, the latency of a chain of dependent node hashes in a single wave each way, and the time
+// of one narrow tree level in a 1024-lane workgroup (LDS in, hash, LDS + global out, barrier) with 1 .. 64 nodes.
 // Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -Istark_rs_amd/csrc tools/quad_hash_test.hip -o tools/quad_hash_test
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
 #include <vector>
 #include "hash_quad.h"
+#include "hash_hex.h"
 
 __global__ void single_kernel(const uint32_t *in, uint32_t *out, int n, int chain) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -33,6 +35,64 @@ __global__ void quad_kernel(const uint32_t *in, uint32_t *out, int n, int chain)
     out[8 * i + 4 + L.q] = hi;
 }
 
+__global__ void hex_kernel(const uint32_t *in, uint32_t *out, int n, int chain) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, i = t >> 4;
+    if (i >= n) return;
+    const hashx::Lane L = hashx::make_lane(threadIdx.x);
+    const uint32_t w = threadIdx.x & 15u, j = w >> 2;
+    uint32_t ml = hashx::message(in[16 * i + j], in[16 * i + 4 + j], L);
+    const uint32_t mr = hashx::message(in[16 * i + 8 + j], in[16 * i + 12 + j], L);
+    uint32_t x = 0;
+    for (int c = 0; c < chain; c++) {
+        x = hashx::node_hash(ml, mr, L);
+        ml = x & 0x00FF00FFu;
+    }
+    uint8_t *o = (uint8_t *)(out + 8 * i);
+    o[w] = (uint8_t)x;
+    o[16 + w] = (uint8_t)(x >> 16);
+}
+// one tree level of `half` nodes, `levels` times over (every round hashes the same children): MODE 0 quad, 1 hex
+#define LV_MAX 2048
+template <int MODE> __global__ __launch_bounds__(1024) void level_kernel(const uint32_t *in, uint4 *nodes, uint32_t half, int levels) {
+    __shared__ uint32_t buf[8 * LV_MAX];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < 2 * half; i += 1024)
+        for (int w = 0; w < 8; w++) buf[w * LV_MAX + i] = in[8 * i + w];
+    __syncthreads();
+    const hashq::Lane lane = hashq::make_lane(tid);
+    const hashx::Lane row = hashx::make_lane(tid);
+    uint32_t base = 0;
+    for (int lv = 0; lv < levels; lv++) {
+        if (MODE == 0) {
+            const uint32_t node = tid >> 2;
+            if (node < half) {
+                uint32_t l[8], r[8], lo, hi;
+                for (int w = 0; w < 8; w++) { l[w] = buf[w * LV_MAX + base + 2 * node]; r[w] = buf[w * LV_MAX + base + 2 * node + 1]; }
+                hashq::node_hash(l, r, lane, lo, hi);
+                uint32_t *dst = (uint32_t *)(nodes + 2 * ((size_t)lv * half + node));
+                dst[lane.q] = lo; dst[4 + lane.q] = hi;
+                buf[lane.q * LV_MAX + (base ^ (LV_MAX / 2)) + node] = lo;
+                buf[(4 + lane.q) * LV_MAX + (base ^ (LV_MAX / 2)) + node] = hi;
+            }
+        } else {
+            const uint32_t node = tid >> 4, w = tid & 15u, j = w >> 2;
+            if (node < half) {
+                const uint32_t *src = buf + base + 2 * node;
+                const uint32_t ml = hashx::message(src[j * LV_MAX], src[(4 + j) * LV_MAX], row);
+                const uint32_t mr = hashx::message(src[j * LV_MAX + 1], src[(4 + j) * LV_MAX + 1], row);
+                const uint32_t x = hashx::node_hash(ml, mr, row);
+                uint8_t *dst = (uint8_t *)(nodes + 2 * ((size_t)lv * half + node));
+                dst[w] = (uint8_t)x; dst[16 + w] = (uint8_t)(x >> 16);
+                uint8_t *nb = (uint8_t *)(buf + (base ^ (LV_MAX / 2)) + node);
+                nb[4 * (j * LV_MAX) + (w & 3u)] = (uint8_t)x;
+                nb[4 * ((4 + j) * LV_MAX) + (w & 3u)] = (uint8_t)(x >> 16);
+            }
+        }
+        __syncthreads();
+        // the next round reads the same children again: copy nothing, keep base (the written slot is scratch)
+    }
+}
+
 int main() {
     const int n = 1000;
     std::vector<uint32_t> h(16 * n);
@@ -52,22 +112,49 @@ int main() {
         (void)hipMemcpy(b.data(), db, b.size() * 4, hipMemcpyDeviceToHost);
         for (int i = 0; i < 8 * n; i++) bad += a[i] != b[i];
         printf("chain %d: %d of %d digest words differ (first digest %08x %08x vs %08x %08x)\n", chain, bad, 8 * n, a[0], a[1], b[0], b[1]);
+        if (chain == 1) {
+            hex_kernel<<<(16 * n + 255) / 256, 256>>>(din, db, n, 1);
+            (void)hipMemcpy(b.data(), db, b.size() * 4, hipMemcpyDeviceToHost);
+            int badx = 0;
+            for (int i = 0; i < 8 * n; i++) badx += a[i] != b[i];
+            printf("row of sixteen: %d of %d digest words differ\n", badx, 8 * n);
+            bad += badx;
+        }
     }
     // latency: one wave, a chain of dependent node hashes
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const int chain = 200;
-    for (int which = 0; which < 2; which++) {
+    for (int which = 0; which < 3; which++) {
         for (int rep = 0; rep < 2; rep++) {
             (void)hipEventRecord(e0);
             if (which == 0) single_kernel<<<1, 64>>>(din, da, 64, chain);
-            else quad_kernel<<<1, 64>>>(din, db, 16, chain);
+            else if (which == 1) quad_kernel<<<1, 64>>>(din, db, 16, chain);
+            else hex_kernel<<<1, 64>>>(din, db, 4, chain);
             (void)hipEventRecord(e1);
             (void)hipEventSynchronize(e1);
         }
         float ms;
         (void)hipEventElapsedTime(&ms, e0, e1);
-        printf("%s: %.2f us per node hash in a single wave\n", which ? "quad lanes " : "single lane", 1e3 * ms / chain);
+        printf("%s: %.2f us per node hash in a single wave\n", which == 0 ? "single lane   " : which == 1 ? "quad lanes    " : "row of sixteen", 1e3 * ms / chain);
+    }
+    uint4 *dn;
+    (void)hipMalloc(&dn, (size_t)400 * 64 * 32);
+    for (uint32_t half : {64u, 32u, 16u, 4u, 1u}) {
+        float t[2];
+        for (int mode = 0; mode < 2; mode++) {
+            const int levels = 400;
+            for (int rep = 0; rep < 2; rep++) {
+                (void)hipEventRecord(e0);
+                if (mode == 0) level_kernel<0><<<1, 1024>>>(din, dn, half, levels);
+                else level_kernel<1><<<1, 1024>>>(din, dn, half, levels);
+                (void)hipEventRecord(e1);
+                (void)hipEventSynchronize(e1);
+            }
+            (void)hipEventElapsedTime(&t[mode], e0, e1);
+            t[mode] = 1e3f * t[mode] / levels;
+        }
+        printf("level of %2u nodes in a 1024-lane workgroup: quad %.2f us, row of sixteen %.2f us\n", half, t[0], t[1]);
     }
     return bad != 0;
 }
