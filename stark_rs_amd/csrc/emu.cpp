@@ -487,6 +487,26 @@ extern "C" void emu_node_hash_hex(const uint8_t *pairs, size_t n, uint8_t *out) 
     }
 }
 
+// one Fiat-Shamir round over the row (hashx::fs_absorb / fs_challenge): state in, state and challenge out
+extern "C" void emu_fs_round_hex(uint32_t *fs_words, const uint8_t *root, uint64_t *alpha) {
+    const hashx::Lane L = hashx::make_lane(0);
+    uint32_t r[8];
+    memcpy(r, root, 32);
+    H16 lo, hi, x;
+    for (int w = 0; w < 16; w++) { lo.v[w] = r[w >> 2]; hi.v[w] = r[4 + (w >> 2)]; x.v[w] = fs_words[w]; }
+    x = hashx::fs_absorb(x, hashx::message(lo, hi, L), L);
+    for (int w = 0; w < 16; w++) fs_words[w] = x.v[w];
+    const H16 y = hashx::fs_challenge(x, L);
+    *alpha = 0;
+    for (int k = 0; k < 8; k++) *alpha |= (uint64_t)(y.v[k] & 0xFFu) << (8 * k);
+}
+// the same round by a single lane (hashc::fs_absorb_root, what the row form replaces)
+extern "C" void emu_fs_round(uint32_t *fs_words, const uint8_t *root, uint64_t *alpha) {
+    uint32_t m[8];
+    memcpy(m, root, 32);
+    hashc::fs_absorb_root(fs_words, m, nullptr, alpha);
+}
+
 // rows of W residues, row-major in `v`: pairs through row_hash2 when W <= 4, the rest through row_hash
 extern "C" void emu_row_hash(const uint32_t *v, size_t n_rows, int W, uint8_t *out) {
     size_t i = 0;

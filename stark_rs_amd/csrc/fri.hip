@@ -8,6 +8,7 @@
 // copy the serialized proof back.
 #include "fri_core.h"
 #include "hash_core.h"
+#include "hash_hex.h"
 #include "internal.h"
 
 int launch_merkle(smi_ctx *ctx, const uint32_t *d_elems, size_t n, uint8_t *d_nodes);
@@ -51,22 +52,20 @@ __global__ void fs_init_kernel(FsState *fs, const uint8_t *ride_src = nullptr, u
 
 // absorb the root at `root`, append it (tag 0 + 32 bytes, src/stream.rs:39-42) to the proof
 // buffer, and if alpha_out != nullptr draw the challenge.
+// (both over the first sixteen lanes, one state word each: hash_hex.h)
 __global__ void fs_round_kernel(FsState *fs, const uint32_t *root, uint8_t *proof_slot, uint64_t *alpha_out) {
-    if (threadIdx.x || blockIdx.x) return;
-    uint32_t m[8];
-    for (int i = 0; i < 8; i++) m[i] = root[i];
-    hashc::fs_absorb_root(fs->s, m, proof_slot, alpha_out);
+    if (threadIdx.x >= 16 || blockIdx.x) return;
+    const hashx::Lane row = hashx::make_lane(threadIdx.x);
+    const uint32_t j = threadIdx.x >> 2;
+    hashx::fs_absorb_root(fs->s, hashx::message(root[j], root[4 + j], row), row, proof_slot, alpha_out);
 }
 
 // challenge without absorbing (src/fri.rs:272: the index-sampling seed)
 __global__ void fs_challenge_kernel(const FsState *fs, uint64_t *alpha_out) {
-    if (threadIdx.x || blockIdx.x) return;
-    hashc::State st;
-    for (int i = 0; i < 16; i++) st.s[i] = fs->s[i];
-    for (int k = 0; k < 8; k++) hashc::mix(st);
-    uint32_t d[8];
-    hashc::to_words(st, d);
-    *alpha_out = (uint64_t)d[0] | ((uint64_t)d[1] << 32);
+    if (threadIdx.x >= 16 || blockIdx.x) return;
+    const hashx::Lane row = hashx::make_lane(threadIdx.x);
+    const uint64_t a = hashx::low_bytes_u64(hashx::fs_challenge(fs->s[threadIdx.x], row));
+    if (threadIdx.x == 0) *alpha_out = a;
 }
 
 // Fri::sample_indices (src/fri.rs:176-213) with seed = Hash::from_u64(challenge).0

@@ -321,12 +321,13 @@ __device__ __forceinline__ uint32_t top_chunk(const uint32_t *__restrict__ elems
 }
 
 // the Fiat-Shamir round of the root by the launch that produced it (TopHook)
+// (by the first sixteen lanes, one state word each: hash_hex.h)
 __device__ __forceinline__ void top_finish(const TopHook &hook, const uint32_t *buf, uint32_t base) {
-    if (hook.fs_words && threadIdx.x == 0 && gridDim.x == 1 && blockIdx.y == 0) {   // the root sits in slot `base` of every word row
-        uint32_t m[8];
-#pragma unroll
-        for (int w = 0; w < 8; w++) m[w] = buf[w * SMI_TOP_MAX + base];
-        hashc::fs_absorb_root(hook.fs_words, m, hook.proof_slot, hook.alpha_out);
+    if (hook.fs_words && threadIdx.x < 16 && gridDim.x == 1 && blockIdx.y == 0) {   // the root sits in slot `base` of every word row
+        const hashx::Lane row = hashx::make_lane(threadIdx.x);
+        const uint32_t j = threadIdx.x >> 2;
+        hashx::fs_absorb_root(hook.fs_words, hashx::message(buf[j * SMI_TOP_MAX + base], buf[(4 + j) * SMI_TOP_MAX + base], row), row,
+                              hook.proof_slot, hook.alpha_out);
     }
 }
 // one tree whose leaves are the fold of the round before (LeafSrc, LEAF_FOLD), chunk by chunk
@@ -365,11 +366,11 @@ __global__ __launch_bounds__(SMI_TOP_THREADS) void fri_tail_kernel(const FriTail
     for (uint32_t k = 0; k < a.n_rounds; k++) {
         const FriTailRound R = a.r[k];
         const uint32_t base = top_chunk<true>(R.cw, (uint4 *)R.nodes, R.len, 0, R.len, 0, 0, 0, buf);
-        if (tid == 0) {
-            uint32_t m[8];
-#pragma unroll
-            for (int w = 0; w < 8; w++) m[w] = buf[w * SMI_TOP_MAX + base];
-            hashc::fs_absorb_root(a.fs_words, m, R.proof_slot, R.alpha_out);   // no challenge after the last root
+        if (tid < 16) {
+            const hashx::Lane row = hashx::make_lane(tid);
+            const uint32_t j = tid >> 2;
+            hashx::fs_absorb_root(a.fs_words, hashx::message(buf[j * SMI_TOP_MAX + base], buf[(4 + j) * SMI_TOP_MAX + base], row), row,
+                                  R.proof_slot, R.alpha_out);   // no challenge after the last root
             __threadfence_block();
         }
         __syncthreads();   // the challenge is in memory; buf may be overwritten by the next round

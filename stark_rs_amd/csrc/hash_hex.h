@@ -167,5 +167,42 @@ SMI_XD word node_hash(word ml, word mr, const Lane &L) {
 // the lane's message word from the natural-layout words j = w >> 2 and 4 + j of a digest
 SMI_XD word message(word lo, word hi, const Lane &L) { return perm8v(hi, lo, L.sel); }
 
+// One Fiat-Shamir round of Fri::commit over the row (hashc::fs_absorb_root lane by lane: 3.2 us of a tree's last launch when
+// a single lane runs it, profiles/r03_z_tophash_ubench.log).  x = the lane's word of the transcript's sponge state (fully
+// applied, as hashc::fs_absorb_root keeps it in memory), m = its two bytes of the root: absorb and mix (src/hash.rs:14-23).
+SMI_XD word fs_absorb(word x, word m, const Lane &L) { return mix<false>(absorb(x, m, L), L) + L.rc; }
+// FiatShamir::challenge (src/fiat_shamir.rs:19-25) of the state x: the eight closing mixes on a copy; bits 0..7 of lanes
+// 0..7 are the challenge's bytes, little end first
+SMI_XD word fs_challenge(word x, const Lane &L) {
+    x = mix<false>(x, L);
+#pragma unroll
+    for (int k = 0; k < 7; k++) x = mix<true>(x, L);
+    return x + L.rc;
+}
+#if !defined(SMI_HEX_EMU) && defined(__HIPCC__)
+// the low bytes of lanes 0..7 of the wave's first row as one u64 (wave-uniform)
+__device__ __forceinline__ uint64_t low_bytes_u64(uint32_t y) {
+    uint64_t a = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) a |= (uint64_t)((uint32_t)__builtin_amdgcn_readlane((int)y, k) & 0xFFu) << (8 * k);
+    return a;
+}
+// hashc::fs_absorb_root by lanes 0..15 of a wave (all sixteen active, no other row of the wave inside this call): absorb the
+// root, append it to the proof (tag 0 + 32 bytes), draw the challenge unless alpha_out == nullptr
+__device__ __forceinline__ void fs_absorb_root(uint32_t *fs_words, uint32_t m, const Lane &L, uint8_t *proof_slot, uint64_t *alpha_out) {
+    const uint32_t x = fs_absorb(fs_words[L.w], m, L);
+    fs_words[L.w] = x;
+    if (proof_slot) {
+        if (L.w == 0) proof_slot[0] = 0;
+        proof_slot[1 + L.w] = (uint8_t)m;
+        proof_slot[17 + L.w] = (uint8_t)(m >> 16);
+    }
+    if (alpha_out) {
+        const uint64_t a = low_bytes_u64(fs_challenge(x, L));
+        if (L.w == 0) *alpha_out = a;
+    }
+}
+#endif
+
 }  // namespace hashx
 #endif

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "hash_core.h"
+#include "hash_hex.h"
 #include "internal.h"
 #include "mgpu_core.h"
 
@@ -30,20 +31,19 @@ int fri_run(smi_ctx *ctx, const smi_fri_cfg *cfg, const uint32_t *d_codeword, si
 // the roots are named by a pointer table, or (root_ptrs == nullptr) sit root_stride bytes apart from root0 on
 __global__ void fs_weights_kernel(const uint8_t *const *root_ptrs, uint32_t n, uint64_t *weights, uint32_t *roots_out,
                                   uint32_t *weights_m = nullptr, Fp F = Fp{0, 0, 0, 0}, const uint8_t *root0 = nullptr, size_t root_stride = 0) {
-    if (threadIdx.x || blockIdx.x) return;
-    hashc::State st;
-    hashc::init(st);
+    if (threadIdx.x >= 16 || blockIdx.x) return;   // one state word per lane of the first row (hash_hex.h)
+    const hashx::Lane row = hashx::make_lane(threadIdx.x);
+    const uint32_t w = threadIdx.x, j = w >> 2;
+    uint32_t x = row.init;
     for (uint32_t c = 0; c < n; c++) {
         const uint32_t *root = (const uint32_t *)(root_ptrs ? root_ptrs[c] : root0 + (size_t)c * root_stride);
-        uint32_t m[8];
-        for (int i = 0; i < 8; i++) roots_out[8 * c + i] = m[i] = root[i];   // gathered: one copy to the host
-        hashc::absorb_chunk32(st, m);
-        hashc::State ch = st;
-        for (int k = 0; k < 8; k++) hashc::mix(ch);
-        uint32_t d[8];
-        hashc::to_words(ch, d);
-        weights[c] = (uint64_t)d[0] | ((uint64_t)d[1] << 32);
-        if (weights_m) weights_m[c] = to_mont_u64(weights[c], F);
+        if (w < 8) roots_out[8 * c + w] = root[w];   // gathered: one copy to the host
+        x = hashx::fs_absorb(x, hashx::message(root[j], root[4 + j], row), row);
+        const uint64_t wt = hashx::low_bytes_u64(hashx::fs_challenge(x, row));
+        if (w == 0) {
+            weights[c] = wt;
+            if (weights_m) weights_m[c] = to_mont_u64(wt, F);
+        }
     }
 }
 

@@ -126,6 +126,25 @@ def test_emulated_hex_node_hash(emu, oracle):
         assert bytes(out[i]) == o.hash_combine(bytes(pairs[i, :32]), bytes(pairs[i, 32:])), i
 
 
+def test_emulated_hex_fiat_shamir_round(emu, oracle):
+    """hashx::fs_absorb / fs_challenge -- the Fiat-Shamir round at the end of a tree's last launch, over a row of sixteen
+    lanes: a transcript of 12 roots against the single-lane form (state bytes and challenges) and against the oracle's
+    FiatShamir (src/fiat_shamir.rs:9-25) run on the same roots."""
+    rng = np.random.default_rng(11)
+    st_a = (C.c_uint32 * 16)(*[int(p_) * 0x00010001 for p_ in [2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47, 53]])
+    st_b = (C.c_uint32 * 16)(*st_a)
+    fs = oracle.FiatShamir()
+    for k in range(12):
+        root = bytes(rng.integers(0, 256, 32, dtype=np.uint8)) if k else bytes(32)
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        emu.emu_fs_round_hex(st_a, root, C.byref(a))
+        emu.emu_fs_round(st_b, root, C.byref(b))
+        fs.absorb(root)
+        assert a.value == b.value == fs.challenge(), k
+        # the stored words agree on every meaningful bit (bits 0..7 of either 16-bit lane)
+        assert [x & 0x00FF00FF for x in st_a] == [x & 0x00FF00FF for x in st_b], k
+
+
 @pytest.mark.parametrize("L,plan", [
     (18, "9.3,9.3"), (18, "9.5,9.4"), (18, "10.4,8.4"), (18, "6.6,6.6,6.6"), (19, "7.6,6.6,6.6"), (20, "10.2,10.2"),
     (20, "10.4,10.3"), (20, "7.5,7.5,6.6"), (20, "8.6,6.6,6.6"), (21, "8.5,7.6,6.6"), (21, "9.4,6.6,6.6"),

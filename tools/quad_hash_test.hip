@@ -93,6 +93,65 @@ template <int MODE> __global__ __launch_bounds__(1024) void level_kernel(const u
     }
 }
 
+// the last launch of a tree as merkle_top_kernel<false> runs it (256 chunk roots -> root, then the Fiat-Shamir round by
+// lane 0), with a time stamp (s_memrealtime, 100 MHz) after every phase: where do its ~18 us go?
+__global__ __launch_bounds__(1024) void final_kernel(const uint32_t *in, uint4 *nodes, uint32_t chunk, uint32_t *fs_words, uint64_t *alpha, uint64_t *stamps) {
+    __shared__ uint32_t buf[8 * LV_MAX];
+    const uint32_t tid = threadIdx.x;
+    int ns = 0;
+    auto stamp = [&]() { if (tid == 0) stamps[ns] = __builtin_amdgcn_s_memrealtime(); ns++; };
+    stamp();
+    for (uint32_t i = tid; i < chunk; i += 1024) {
+        const uint4 a = ((const uint4 *)in)[2 * i], b = ((const uint4 *)in)[2 * i + 1];
+        buf[0 * LV_MAX + i] = a.x; buf[1 * LV_MAX + i] = a.y; buf[2 * LV_MAX + i] = a.z; buf[3 * LV_MAX + i] = a.w;
+        buf[4 * LV_MAX + i] = b.x; buf[5 * LV_MAX + i] = b.y; buf[6 * LV_MAX + i] = b.z; buf[7 * LV_MAX + i] = b.w;
+    }
+    __syncthreads();
+    stamp();
+    const hashq::Lane lane = hashq::make_lane(tid);
+    const hashx::Lane row = hashx::make_lane(tid);
+    uint32_t base = 0;
+    size_t off = 0;
+    for (uint32_t cnt = chunk; cnt > 1; cnt >>= 1) {
+        const uint32_t half = cnt >> 1;
+        if (half <= 16) {
+            const uint32_t node = tid >> 4, w = tid & 15u, j = w >> 2;
+            if (node < half) {
+                const uint32_t *src = buf + base + 2 * node;
+                const uint32_t ml = hashx::message(src[j * LV_MAX], src[(4 + j) * LV_MAX], row);
+                const uint32_t mr = hashx::message(src[j * LV_MAX + 1], src[(4 + j) * LV_MAX + 1], row);
+                const uint32_t x = hashx::node_hash(ml, mr, row);
+                uint8_t *dst = (uint8_t *)(nodes + 2 * (off + node));
+                dst[w] = (uint8_t)x; dst[16 + w] = (uint8_t)(x >> 16);
+                uint8_t *nb = (uint8_t *)(buf + (base ^ (LV_MAX / 2)) + node);
+                nb[4 * (j * LV_MAX) + (w & 3u)] = (uint8_t)x;
+                nb[4 * ((4 + j) * LV_MAX) + (w & 3u)] = (uint8_t)(x >> 16);
+            }
+        } else {
+            const uint32_t node = tid >> 2;
+            if (node < half) {
+                uint32_t l[8], r[8], lo, hi;
+                for (int w = 0; w < 8; w++) { l[w] = buf[w * LV_MAX + base + 2 * node]; r[w] = buf[w * LV_MAX + base + 2 * node + 1]; }
+                hashq::node_hash(l, r, lane, lo, hi);
+                uint32_t *dst = (uint32_t *)(nodes + 2 * (off + node));
+                dst[lane.q] = lo; dst[4 + lane.q] = hi;
+                buf[lane.q * LV_MAX + (base ^ (LV_MAX / 2)) + node] = lo;
+                buf[(4 + lane.q) * LV_MAX + (base ^ (LV_MAX / 2)) + node] = hi;
+            }
+        }
+        off += half;
+        base ^= LV_MAX / 2;
+        __syncthreads();
+        stamp();
+    }
+    if (tid == 0) {
+        uint32_t m[8];
+        for (int w = 0; w < 8; w++) m[w] = buf[w * LV_MAX + base];
+        hashc::fs_absorb_root(fs_words, m, nullptr, alpha);
+    }
+    stamp();
+}
+
 int main() {
     const int n = 1000;
     std::vector<uint32_t> h(16 * n);
@@ -140,6 +199,28 @@ int main() {
     }
     uint4 *dn;
     (void)hipMalloc(&dn, (size_t)400 * 64 * 32);
+    {
+        uint32_t *dfs; uint64_t *dal, *dst;
+        (void)hipMalloc(&dfs, 64); (void)hipMalloc(&dal, 8); (void)hipMalloc(&dst, 8 * 32);
+        (void)hipMemset(dfs, 1, 64);
+        for (uint32_t chunk : {256u, 64u, 512u}) {
+            float ms = 0;
+            for (int rep = 0; rep < 3; rep++) {
+                (void)hipEventRecord(e0);
+                final_kernel<<<1, 1024>>>(din, dn, chunk, dfs, dal, dst);
+                (void)hipEventRecord(e1);
+                (void)hipEventSynchronize(e1);
+                (void)hipEventElapsedTime(&ms, e0, e1);
+            }
+            uint64_t st[32];
+            (void)hipMemcpy(st, dst, sizeof st, hipMemcpyDeviceToHost);
+            int levels = 0;
+            while ((1u << levels) < chunk) levels++;
+            printf("last launch of a tree, %u digests -> root + Fiat-Shamir: %.1f us between events; load %.2f us, levels", chunk, 1e3 * ms, (st[1] - st[0]) * 0.01);
+            for (int l = 0; l < levels; l++) printf(" %.2f", (st[2 + l] - st[1 + l]) * 0.01);
+            printf(", Fiat-Shamir round %.2f us, sum %.2f us\n", (st[2 + levels] - st[1 + levels]) * 0.01, (st[2 + levels] - st[0]) * 0.01);
+        }
+    }
     for (uint32_t half : {64u, 32u, 16u, 4u, 1u}) {
         float t[2];
         for (int mode = 0; mode < 2; mode++) {
