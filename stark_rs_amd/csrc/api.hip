@@ -83,8 +83,6 @@ int smi_ctx_create(uint64_t p, uint64_t g, int device, smi_ctx **out) {
         ctx->own_stream = true;
         if (hipMalloc((void **)&ctx->d_flag, sizeof(int)) != hipSuccess) { rc = SMI_ERR_OOM; break; }
         if (hipMemsetAsync(ctx->d_flag, 0, sizeof(int), ctx->stream) != hipSuccess) { rc = SMI_ERR_HIP; break; }
-        if (hipMalloc((void **)&ctx->d_tickets, SMI_TICKETS * sizeof(uint32_t)) != hipSuccess) { rc = SMI_ERR_OOM; break; }
-        if (hipMemsetAsync(ctx->d_tickets, 0, SMI_TICKETS * sizeof(uint32_t), ctx->stream) != hipSuccess) { rc = SMI_ERR_HIP; break; }
         for (int dir = 0; dir < 2 && rc == SMI_OK; dir++) {
             GeomSpec sp[3];
             ntt_table_specs(ctx->fs, dir, sp);
@@ -126,7 +124,6 @@ void smi_ctx_destroy(smi_ctx *ctx) {
     }
     if (ctx->pin_out) (void)hipHostFree(ctx->pin_out);
     (void)hipFree(ctx->d_flag);
-    (void)hipFree(ctx->d_tickets);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

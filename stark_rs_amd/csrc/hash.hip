@@ -322,61 +322,30 @@ __device__ __forceinline__ uint32_t top_chunk(const uint32_t *__restrict__ elems
 
 // the Fiat-Shamir round of the root by the launch that produced it (TopHook)
 // (by the first sixteen lanes, one state word each: hash_hex.h)
-__device__ __forceinline__ void top_finish(const TopHook &hook, const uint32_t *buf, uint32_t base, bool root_here) {
-    if (hook.fs_words && threadIdx.x < 16 && root_here && blockIdx.y == 0) {   // the root sits in slot `base` of every word row
+__device__ __forceinline__ void top_finish(const TopHook &hook, const uint32_t *buf, uint32_t base) {
+    if (hook.fs_words && threadIdx.x < 16 && gridDim.x == 1 && blockIdx.y == 0) {   // the root sits in slot `base` of every word row
         const hashx::Lane row = hashx::make_lane(threadIdx.x);
         const uint32_t j = threadIdx.x >> 2;
         hashx::fs_absorb_root(hook.fs_words, hashx::message(buf[j * SMI_TOP_MAX + base], buf[(4 + j) * SMI_TOP_MAX + base], row), row,
                               hook.proof_slot, hook.alpha_out);
     }
 }
-// The chunk workgroup that finishes LAST goes on with the tree of the chunk roots (ticket != nullptr), instead of a second
-// launch for it: every lane publishes its digests (device-scope fence), lane 0 draws a ticket, and the workgroup that draws
-// the last one -- all others have published by then -- acquires and continues; nobody waits for anybody.  The counter is
-// back at zero when the launch ends.  Returns true in that one workgroup.
-__device__ __forceinline__ bool last_chunk_workgroup(uint32_t *ticket) {
-    __shared__ uint32_t s_last;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t t = atomicAdd(ticket, 1u);
-        s_last = t == gridDim.x - 1;
-        if (s_last) atomicExch(ticket, 0u);
-    }
-    __syncthreads();
-    if (!s_last) return false;
-    __threadfence();
-    return true;
-}
-// chunk workgroups of one launch -> the tree's root in `buf` of the workgroup that returns true (all of them if there is
-// only one chunk); false: this workgroup is done
-template <bool FROM_ELEMS>
-__device__ __forceinline__ bool top_roots(uint4 *nodes, size_t n, uint32_t lvl_in, uint32_t chunk, uint32_t *ticket, uint32_t *buf, uint32_t &base) {
-    if (gridDim.x == 1) return true;
-    if (!ticket) return false;
-    if (!last_chunk_workgroup(ticket + blockIdx.y)) return false;
-    base = top_chunk<false>(nullptr, nodes, n, lvl_in + (uint32_t)(__ffs((int)chunk) - 1), gridDim.x, 0, 0, 0, buf);
-    return true;
-}
 // one tree whose leaves are the fold of the round before (LeafSrc, LEAF_FOLD), chunk by chunk
-__global__ __launch_bounds__(SMI_TOP_THREADS) void merkle_top_fold_kernel(uint4 *nodes, size_t n, uint32_t chunk, TopHook hook, const LeafSrc src,
-                                                                           uint32_t *ticket) {
+__global__ __launch_bounds__(SMI_TOP_THREADS) void merkle_top_fold_kernel(uint4 *nodes, size_t n, uint32_t chunk, TopHook hook, const LeafSrc src) {
     __shared__ uint32_t buf[8 * SMI_TOP_MAX];
-    uint32_t base = top_chunk<true, true>(src.cw_out, nodes, n, 0, chunk, (size_t)blockIdx.x * chunk, 0, 0, buf, &src);
-    const bool root_here = top_roots<true>(nodes, n, 0, chunk, ticket, buf, base);
-    top_finish(hook, buf, base, root_here);
+    const uint32_t base = top_chunk<true, true>(src.cw_out, nodes, n, 0, chunk, (size_t)blockIdx.x * chunk, 0, 0, buf, &src);
+    top_finish(hook, buf, base);
 }
 template <bool FROM_ELEMS>
 __global__ __launch_bounds__(SMI_TOP_THREADS) void merkle_top_kernel(const uint32_t *__restrict__ elems, uint4 *nodes, size_t n,
                                                                       uint32_t lvl_in, uint32_t chunk, size_t elem_stride,
                                                                       size_t node_stride, uint32_t row_cols, size_t row_stride,
-                                                                      TopHook hook, uint32_t *ticket) {
+                                                                      TopHook hook) {
     __shared__ uint32_t buf[8 * SMI_TOP_MAX];
     elems += (size_t)blockIdx.y * elem_stride;
     nodes += (size_t)blockIdx.y * node_stride;
-    uint32_t base = top_chunk<FROM_ELEMS>(elems, nodes, n, lvl_in, chunk, (size_t)blockIdx.x * chunk, row_cols, row_stride, buf);
-    const bool root_here = top_roots<FROM_ELEMS>(nodes, n, FROM_ELEMS ? 0 : lvl_in, chunk, ticket, buf, base);
-    top_finish(hook, buf, base, root_here);
+    const uint32_t base = top_chunk<FROM_ELEMS>(elems, nodes, n, lvl_in, chunk, (size_t)blockIdx.x * chunk, row_cols, row_stride, buf);
+    top_finish(hook, buf, base);
 }
 
 // The tail of Fri::commit (reference src/fri.rs:116-148) in ONE launch: once a codeword has at most
@@ -680,39 +649,31 @@ static int launch_merkle_impl(smi_ctx *ctx, const uint32_t *d_elems, size_t n, u
         }
         const size_t n_chunks = count / chunk;
         if (chunk <= SMI_TOP_MAX && n_chunks * n_trees <= TOP_BLOCKS) {
-            // the chunk roots' own tree in the same launch, by the workgroup that finishes last (last_chunk_workgroup)
-            static const bool tickets_on = getenv("SMI_MERKLE_TICKET") && atoi(getenv("SMI_MERKLE_TICKET"));
-            uint32_t *ticket = tickets_on && n_chunks > 1 && n_chunks <= SMI_TOP_MAX && n_trees <= SMI_TICKETS ? ctx->d_tickets : nullptr;
-            const double roots_out = ticket ? 1.0 : (double)n_chunks;   // digests left when the launch ends
-            const double hashed = (from_elems ? 2.0 * (double)count : (double)count) - roots_out;
+            const double hashed = (from_elems ? 2.0 * (double)count : (double)count) - (double)n_chunks;
             // mix_state evaluations: 9 per single-element leaf (one more per extra 32-byte chunk of a row), 10 per node
             const double leaf_mixes = 8.0 + (row_cols ? (double)((row_cols + 3) / 4) : 1.0);
-            const double mixes = (from_elems ? leaf_mixes * (double)count : 0.0) + 10.0 * ((double)count - roots_out);
+            const double mixes = (from_elems ? leaf_mixes * (double)count : 0.0) + 10.0 * ((double)count - (double)n_chunks);
             ProfScope ps(ctx, "merkle_top_kernel", ((from_elems ? 4.0 * (row_cols ? row_cols : 1) : 32.0) * (double)count + 32.0 * hashed) * n_trees,
                          mixes * n_trees);
             const dim3 grid((uint32_t)n_chunks, n_trees);
             TopHook h{nullptr, nullptr, nullptr};
-            if (hook && (n_chunks == 1 || ticket) && n_trees == 1) {   // this launch ends with the root
+            if (hook && n_chunks == 1 && n_trees == 1) {   // this launch ends with the root
                 h = *hook;
                 *hook_done = true;
             }
             if (from_elems && src) {
                 if (src->kind != LEAF_FOLD || n_trees != 1 || row_cols) return smi_fail(ctx, SMI_ERR_BAD_ARG, "merkle: the chunk kernel computes folded leaves only");
-                merkle_top_fold_kernel<<<grid, SMI_TOP_THREADS, 0, ctx->stream>>>(nodes, n, (uint32_t)chunk, h, *src, ticket);
+                merkle_top_fold_kernel<<<grid, SMI_TOP_THREADS, 0, ctx->stream>>>(nodes, n, (uint32_t)chunk, h, *src);
             } else if (from_elems)
-                merkle_top_kernel<true><<<grid, SMI_TOP_THREADS, 0, ctx->stream>>>(d_elems, nodes, n, 0, (uint32_t)chunk, elem_stride, node_stride, row_cols, row_stride, h, ticket);
+                merkle_top_kernel<true><<<grid, SMI_TOP_THREADS, 0, ctx->stream>>>(d_elems, nodes, n, 0, (uint32_t)chunk, elem_stride, node_stride, row_cols, row_stride, h);
             else
-                merkle_top_kernel<false><<<grid, SMI_TOP_THREADS, 0, ctx->stream>>>(nullptr, nodes, n, lvl, (uint32_t)chunk, 0, node_stride, 0, 0, h, ticket);
+                merkle_top_kernel<false><<<grid, SMI_TOP_THREADS, 0, ctx->stream>>>(nullptr, nodes, n, lvl, (uint32_t)chunk, 0, node_stride, 0, 0, h);
             HIP_TRY(ctx, hipGetLastError());
             from_elems = false;
             uint32_t up = 0;
             while (((size_t)1 << up) < chunk) up++;
             lvl += up;
             count = n_chunks;
-            if (ticket) {   // the launch went on to the root
-                lvl = depth;
-                count = 1;
-            }
             continue;
         }
         uint32_t K = depth - lvl < KMAX ? depth - lvl : KMAX;

@@ -40,7 +40,6 @@ struct smi_ctx {
     void *tmp[4] = {nullptr, nullptr, nullptr, nullptr};  // staging buffers of the host-buffer entry points
     size_t tmp_bytes[4] = {0, 0, 0, 0};
     int *d_flag = nullptr;         // non-canonical input flag
-    uint32_t *d_tickets = nullptr; // SMI_TICKETS counters, zero between launches: which chunk workgroup of a tree finishes last (hash.hip)
     void *pin[2] = {nullptr, nullptr};          // pinned chunks of the large host <-> device transfers
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
     void *pin_out = nullptr;       // pinned landing buffer of a prove's results (proof bytes, challenges, indices, roots)
@@ -167,7 +166,6 @@ inline uint32_t h_root(const smi_ctx *c, uint32_t log_n) {  // primitive 2^log_n
 // One launch for the last rounds of Fri::commit (hash.hip, fri_tail_kernel): round k hashes and commits
 // cw (len elements), runs the Fiat-Shamir round of its root and, unless next == nullptr (the last
 // round), folds into next with the round's x^-1 table S.
-#define SMI_TICKETS 64   // trees per batched Merkle launch that can finish in their chunk launch (smi_ctx::d_tickets)
 #define SMI_FRI_TAIL_MAX_ROUNDS 12
 #define SMI_FRI_TAIL_MAX_LEN 2048   // = SMI_TOP_MAX of hash.hip
 struct FriTailRound {
