@@ -360,18 +360,16 @@ int smi_dev_fri_fold_shard(smi_ctx *ctx, const uint32_t *d_lo, const uint32_t *d
     return launch_fold_shard(ctx, d_lo, d_hi, count, index0, full_len, d_alpha, offset, omega, d_out);
 }
 
-// misc device block layout
+// misc device block layout (the challenges and the sampled indices are not here: they sit behind the proof, fri_run)
 struct MiscLayout {
-    size_t fs, alphas, seed_ch, top, reduced, layers, total;
+    size_t fs, seed_ch, reduced, layers, total;
 };
 static MiscLayout misc_layout(uint64_t R, uint64_t t) {
     MiscLayout m;
     size_t o = 0;
     m.fs = o; o += sizeof(FsState);
     o = (o + 63) & ~(size_t)63;
-    m.alphas = o; o += 8 * (R + 1);
     m.seed_ch = o; o += 8;
-    m.top = o; o += 8 * (t + 1);
     m.reduced = o; o += 8 * (t + 1);
     o = (o + 63) & ~(size_t)63;
     m.layers = o; o += sizeof(LayerInfo) * (R + 1);
