@@ -575,16 +575,24 @@ static size_t merkle_top_blocks() {
     static const size_t v = [] { const char *e = getenv("SMI_MERKLE_TOP_BLOCKS"); return (size_t)(e ? atoi(e) : 256); }();
     return v;
 }
+// A tree that starts from codeword elements goes to the chunk kernel only once it has at most this many leaves: a chunk's
+// first level is then leaf hashing, nine mixes per leaf by single lanes, which the four-leaves-per-lane kernel does at twice
+// the rate even when it fills a quarter of the chip (tuning knob SMI_MERKLE_ELEMS_LOG, log2)
+static size_t merkle_elems_max() {
+    static const size_t v = [] { const char *e = getenv("SMI_MERKLE_ELEMS_LOG"); return (size_t)1 << (e ? atoi(e) : 19); }();
+    const size_t by_blocks = (size_t)SMI_TOP_MAX * merkle_top_blocks();
+    return v < by_blocks ? v : by_blocks;
+}
 bool merkle_fuses_leaf_source(size_t n) {
     static const bool off = (getenv("SMI_MERKLE_FUSE") && atoi(getenv("SMI_MERKLE_FUSE")) == 0) ||
                             (getenv("SMI_MERKLE_GENERIC") && atoi(getenv("SMI_MERKLE_GENERIC"))) ||
                             (getenv("SMI_MERKLE_K") && atoi(getenv("SMI_MERKLE_K")) != 2);
-    return !off && n >= 8 && (n & (n - 1)) == 0 && n > (size_t)SMI_TOP_MAX * merkle_top_blocks();
+    return !off && n >= 8 && (n & (n - 1)) == 0 && n > merkle_elems_max();
 }
 // ... and with at most that many (and at least two) the first launch is the chunk kernel, which can fold as it reads
 bool merkle_chunks_fold(size_t n) {
     static const bool off = getenv("SMI_MERKLE_FUSE") && atoi(getenv("SMI_MERKLE_FUSE")) == 0;
-    return !off && n >= 2 && (n & (n - 1)) == 0 && n <= (size_t)SMI_TOP_MAX * merkle_top_blocks();
+    return !off && n >= 2 && (n & (n - 1)) == 0 && n <= merkle_elems_max();
 }
 // one tree whose leaves are computed by the launch that hashes them (src.cw_out receives the codeword)
 int launch_merkle_src_fs(smi_ctx *ctx, const LeafSrc &src, size_t n, uint8_t *d_nodes, uint32_t *fs_words, uint8_t *proof_slot,
@@ -648,7 +656,7 @@ static int launch_merkle_impl(smi_ctx *ctx, const uint32_t *d_elems, size_t n, u
             while (chunk < SMI_TOP_MAX && (count / chunk) * n_trees > TOP_BLOCKS) chunk <<= 1;
         }
         const size_t n_chunks = count / chunk;
-        if (chunk <= SMI_TOP_MAX && n_chunks * n_trees <= TOP_BLOCKS) {
+        if (chunk <= SMI_TOP_MAX && n_chunks * n_trees <= TOP_BLOCKS && (!from_elems || row_cols || count <= merkle_elems_max())) {
             const double hashed = (from_elems ? 2.0 * (double)count : (double)count) - (double)n_chunks;
             // mix_state evaluations: 9 per single-element leaf (one more per extra 32-byte chunk of a row), 10 per node
             const double leaf_mixes = 8.0 + (row_cols ? (double)((row_cols + 3) / 4) : 1.0);
