@@ -502,10 +502,10 @@ def main():
         try:
             for _ in range(2):   # warm-up: the first call sizes the device arena, the second allocates it
                 eng.dev_stark_prove(trace.data_ptr(), N_COLS, LOG_ROWS, LOG_BLOWUP, N_TESTS)
-            # five timed proves, each between its own synchronisations; prove_ms = the median's wall time (host call to
+            # nine timed proves, each between its own synchronisations; prove_ms = the median's wall time (host call to
             # proof bytes on the host), stage times from the same prove
             runs = []
-            for _ in range(5):
+            for _ in range(9):
                 barrier()
                 torch.cuda.synchronize()
                 tp = time.perf_counter()
