@@ -77,6 +77,19 @@ inline NttPlan ntt_make_plan(uint32_t L, uint32_t batch = 1) {
         pl.logr[i] = (rem + left - 1) / left;  // ceil: larger digits first
         rem -= pl.logr[i];
     }
+    // 2^23..2^26 in three passes: 256-point columns in 64-column tiles first (256-byte store runs), 512-point lines last, what
+    // is left in the middle (with 64-column tiles while its lines are short).  Measured in the sustained regime at the end of
+    // r03 (profiles/r03_plans5_ab.log, r03_plans6_sizes.log; the earlier sweeps never paired a 16 K-point last tile with a
+    // 64-column first one): 2^25 x 4 extension step 0.698-0.702 -> 0.675-0.678 ms, 2^23 x 4 0.169 -> 0.163, one 2^26-point
+    // transform 0.414-0.421 -> 0.390 ms, 2^24 x 4 within 0.5 % of the even split.
+    if (pl.np == 3 && L >= 23 && L <= 26) {
+        NttPlan o = pl;
+        const int mid = (int)L - 17;
+        o.logr[0] = 8; o.logw[0] = 6;
+        o.logr[1] = mid; o.logw[1] = mid <= 7 ? 6 : 5;
+        o.logr[2] = 9; o.logw[2] = 5;
+        if (ntt_plan_valid(L, o)) return o;
+    }
     // widest lines that fit: strided passes want >= 128-byte runs (W >= 32), see DESIGN.md
     int consumed = 0;
     for (int i = 0; i < pl.np; i++) {
