@@ -18,7 +18,9 @@
 #include "hash_hex.h"
 #include "internal.h"
 
-#define SMI_HASH_THREADS 256
+#ifndef SMI_HASH_THREADS
+#define SMI_HASH_THREADS 256   // tuning builds: -DSMI_HASH_THREADS=128 | 512
+#endif
 #define SMI_ROW_MAX 64   // columns per row leaf
 
 __device__ __forceinline__ size_t level_offset(size_t n, uint32_t lvl) { return 2 * n - ((2 * n) >> lvl); }
