@@ -171,6 +171,33 @@ def test_batched_4096_point_columns(eng, oracle, batch):
     eng.dev_free(d_out)
 
 
+@pytest.mark.parametrize("which,L", [("ref", 23), ("p2", 24), ("p2", 25)])
+def test_batched_transforms_at_the_recut_sizes(eng, eng2, oracle, which, L):
+    """2^23 .. 2^25 points take the digits (8, L - 17, 9) (csrc/ntt_host.h).  A single column goes
+    through ntt_pass_kernel at those shapes (checked against the oracle and the golden hashes elsewhere in this file); three
+    columns with a coset offset take the column-sharing kernels, ntt_pass_cols_kernel<9,5,last> with its output scale among
+    them: every column of the batch must equal the single-column transform of the same input, both directions, and
+    the first column the oracle's radix-2 transform."""
+    o = oracle
+    e, p, g = (eng, P, G) if which == "ref" else (eng2, P2, G2)
+    n, batch = 1 << L, 3
+    w = o.ff_prim_nth_root_g(n, p, g)
+    cols = _vals(o, 900 + L, batch * n, p)
+    d_in, d_out, d_one = e.dev_alloc(batch * n * 4), e.dev_alloc(batch * n * 4), e.dev_alloc(n * 4)
+    e.dev_upload(cols, d_in)
+    for inverse, offset in ((True, 5), (False, 7)):
+        e.dev_ntt(d_in, d_out, L, batch=batch, inverse=inverse, offset=offset)
+        got = e.dev_download(d_out, batch * n).reshape(batch, n)
+        for c in range(batch):
+            e.dev_ntt(d_in + c * n * 4, d_one, L, batch=1, inverse=inverse, offset=offset)
+            assert np.array_equal(got[c], e.dev_download(d_one, n)), (inverse, c)
+        if L == 23:
+            want = o.fast_intt(cols[:n], w, offset, p) if inverse else o.fast_coset_ntt(cols[:n], n, w, offset, p)
+            assert np.array_equal(got[0], want), inverse
+    for ptr in (d_in, d_out, d_one):
+        e.dev_free(ptr)
+
+
 def test_poly_scale(eng, oracle):
     o = oracle
     assert list(eng.poly_scale([1, 2, 3], 2)) == [1, 4, 12]          # mod.rs:439-456
